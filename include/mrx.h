@@ -1,0 +1,196 @@
+/*
+ * mrx.h -- C-ABI of the MI355X batch renderer (libmrx_hip.so).
+ *
+ * This is the drop-in boundary for the reference's per-frame hot path
+ *   Manager::step()                      /root/reference/src/mgr.cpp:529-546
+ * and the state around it that the path needs (construction, tensor export).
+ * The reference's own boundary is the C++ class madRender::Manager
+ * (/root/reference/src/mgr.hpp:29-120); its Python module binds that class
+ * (/root/reference/src/bindings.cpp:123-233).  Everything below Manager --
+ * the un-vendored Madrona executor, RenderingSystem, BatchRenderer and BVH
+ * tracer -- is replaced by the HIP kernels behind these entry points.
+ *
+ * Plain C types only: pointers, sizes, PODs.  No torch, no C++ types.
+ * Every function returns 0 on success or a negative MRX_E_* code;
+ * mrx_last_error() gives the message of the calling thread's last failure.
+ * The library is HIP-only: mrx_create() fails with MRX_E_NO_DEVICE when no
+ * gfx950 device is usable -- there is no CPU fallback.
+ */
+#ifndef MRX_H
+#define MRX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRX_ABI_VERSION 1
+
+enum {
+    MRX_OK = 0,
+    MRX_E_INVALID = -1,     /* bad argument / inconsistent config          */
+    MRX_E_NO_DEVICE = -2,   /* no usable HIP device                        */
+    MRX_E_HIP = -3,         /* a HIP runtime call failed                   */
+    MRX_E_ASSET = -4,       /* an asset file could not be read or parsed   */
+    MRX_E_UNSUPPORTED = -5  /* e.g. segmask in Rasterizer mode             */
+};
+
+/* Manager::RenderMode, /root/reference/src/mgr.hpp:31-34 */
+enum { MRX_MODE_RASTERIZER = 0, MRX_MODE_RAYTRACER = 1 };
+
+/* madRender::ImportedInstance, /root/reference/src/sim.hpp:31-36 (44 bytes,
+ * rotation is w,x,y,z). */
+typedef struct {
+    float position[3];
+    float rotation[4];
+    float scale[3];
+    int32_t object_id;
+} mrx_instance;
+
+/* madRender::ImportedCamera, /root/reference/src/sim.hpp:47-50 (28 bytes). */
+typedef struct {
+    float position[3];
+    float rotation[4];
+} mrx_camera;
+
+/* madRender::Sim::WorldInit, /root/reference/src/sim.hpp:76-82 (16 bytes). */
+typedef struct {
+    uint32_t num_instances;
+    uint32_t instances_offset;
+    uint32_t num_cameras;
+    uint32_t cameras_offset;
+} mrx_world_init;
+
+/* madrona::imp::SourceMaterial as the reference fills it,
+ * /root/reference/src/bindings.cpp:44-49 (28 bytes). */
+typedef struct {
+    float color[4];
+    int32_t texture_idx;    /* -1: untextured */
+    float roughness;
+    float metalness;
+} mrx_material;
+
+/* Manager::GeometryConfig, /root/reference/src/mgr.hpp:36-47. */
+typedef struct {
+    const float *vertices;              /* [num_vertices][3] */
+    const float *uvs;                   /* [num_vertices][2] */
+    const uint32_t *indices;            /* [num_indices]     */
+    const uint32_t *mesh_vertex_offsets;/* [num_meshes]      */
+    const uint32_t *mesh_index_offsets; /* [num_meshes]      */
+    const int32_t *mesh_materials;      /* [num_meshes]      */
+    uint32_t num_vertices;
+    uint32_t num_indices;
+    uint32_t num_meshes;
+} mrx_geometry;
+
+enum {
+    /* also write a per-pixel int32 visibility buffer (world-local triangle
+     * index, -1 = background); parity tests use it for bit-exact checks */
+    MRX_FLAG_VISIBILITY_IDS = 1u << 0
+};
+
+/* Manager::Config + Config::RenderConfig, /root/reference/src/mgr.hpp:49-88.
+ * All pointers are borrowed for the duration of mrx_create() only. */
+typedef struct {
+    uint32_t struct_size;       /* = sizeof(mrx_config), ABI check */
+    int32_t gpu_id;
+    uint32_t num_worlds;
+    int32_t render_mode;
+    uint32_t view_width;
+    uint32_t view_height;
+    mrx_geometry geo;
+    const char *const *asset_paths;
+    uint32_t num_asset_paths;
+    const int32_t *mat_assignments;     /* per asset path, -1 = none */
+    uint32_t num_mat_assignments;
+    const mrx_material *materials;
+    uint32_t num_materials;
+    const char *const *texture_paths;
+    uint32_t num_textures;
+    const mrx_instance *instances;
+    uint32_t num_instances;
+    const mrx_camera *cameras;
+    uint32_t num_cameras;
+    const mrx_world_init *worlds;       /* [num_worlds] */
+    /* build-only knobs (no counterpart in the reference) */
+    void *stream;               /* hipStream_t to launch on; NULL = null stream */
+    uint32_t flags;             /* MRX_FLAG_* */
+    int32_t kernel_variant;     /* 0 = default; see DESIGN.md section 5 */
+} mrx_config;
+
+typedef struct mrx_renderer mrx_renderer;
+
+/* Buffers of mrx_buffer(): the tensors Manager exports,
+ * /root/reference/src/mgr.cpp:547-665 and ExportID /root/reference/src/sim.hpp:19-29. */
+enum {
+    MRX_BUF_RGB = 0,            /* u8  [views,H,W,4]  (Raytracer: [views,res,res,4]) */
+    MRX_BUF_DEPTH = 1,          /* f32 [views,H,W,1]  (Raytracer: [views,res,res])   */
+    MRX_BUF_SEGMASK = 2,        /* i32 [views,res,res], Raytracer only               */
+    MRX_BUF_INSTANCE_POSITION = 3, /* f32 [instances,3]                              */
+    MRX_BUF_INSTANCE_ROTATION = 4, /* f32 [instances,4]  w,x,y,z                     */
+    MRX_BUF_CAMERA_POSITION = 5,   /* f32 [cameras,3]                                */
+    MRX_BUF_CAMERA_ROTATION = 6,   /* f32 [cameras,4]                                */
+    MRX_BUF_VISIBILITY = 7,     /* i32 [views,H,W], needs MRX_FLAG_VISIBILITY_IDS    */
+    MRX_BUF_INSTANCE_SCALE = 8, /* f32 [instances,3]                                 */
+    MRX_NUM_BUFFERS = 9
+};
+
+enum { MRX_DTYPE_U8 = 0, MRX_DTYPE_I32 = 1, MRX_DTYPE_F32 = 2 };
+
+typedef struct {
+    uint32_t num_worlds, num_views, num_instances;
+    uint32_t num_objects, num_triangles, num_materials, num_textures;
+    uint32_t max_world_triangles;   /* most triangles any one world draws  */
+    uint32_t storage_fast, storage_slow; /* pixels per row / rows per view */
+    int32_t device_id;
+    int32_t kernel_variant;
+    uint64_t bytes_per_step;        /* algorithmic HBM bytes of one render */
+} mrx_info_t;
+
+/* -- lifetime: replaces Manager::Manager / ~Manager (mgr.cpp:505-527).
+ *    Like the reference constructor, mrx_create renders the first frame. */
+int mrx_create(const mrx_config *cfg, mrx_renderer **out);
+void mrx_destroy(mrx_renderer *r);
+
+/* -- per-frame: mrx_step == Manager::step (mgr.cpp:529-546); mrx_render is
+ *    its render half (the north star's Manager::render()).  Both enqueue on
+ *    the renderer's stream and return without waiting. */
+int mrx_step(mrx_renderer *r);
+int mrx_render(mrx_renderer *r);
+int mrx_sync(mrx_renderer *r);
+
+/* -- tensor export: replaces Manager::*Tensor()/ *CudaPtr() (mgr.cpp:547-665).
+ *    Returns the device pointer (owned by the renderer, valid until
+ *    mrx_destroy) or NULL on error. */
+void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim,
+                 int *dtype, int *device);
+
+int mrx_info(mrx_renderer *r, mrx_info_t *out);
+void *mrx_stream(mrx_renderer *r);
+
+/* -- measurement: enqueue `steps` back-to-back mrx_render launches between
+ *    two HIP events on the renderer's stream; *ms_total = elapsed device ms.
+ *    Synchronises the stream before returning. */
+int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total);
+
+/* -- loader cross-check (host copies of what was uploaded) */
+int mrx_copy_triangles(mrx_renderer *r, float *tri_pos /*[T][9]*/,
+                       float *tri_uv /*[T][6]*/, int32_t *tri_mat /*[T]*/,
+                       int32_t *obj_first /*[O]*/, int32_t *obj_count /*[O]*/);
+
+/* -- host-only asset readers (no device needed); free results with mrx_free */
+int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv,
+                 uint32_t *num_tris);
+int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width,
+                   uint32_t *height);
+void mrx_free(void *p);
+
+int mrx_device_count(void);
+int mrx_abi_version(void);
+const char *mrx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRX_H */

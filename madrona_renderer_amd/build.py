@@ -1,0 +1,112 @@
+"""In-tree build of the native pieces (no cmake needed):
+
+  libmrx_hip.so         C-ABI + HIP kernels for gfx950      (hipcc)
+  libmadrona_mi355.so   madRender::Manager C++ API          (g++)
+  madrona_renderer.*.so Python module, reference API        (g++ / pybind11)
+
+Everything lands next to this file so the built objects travel with the
+source tree (they are git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+ARCH = "gfx950"
+
+HIP_SOURCES = ["raster.hip", "mrx_api.cpp", "assets.cpp"]
+HIP_DEPS = HIP_SOURCES + ["raster.hpp", "assets.hpp", "../../include/mrx.h"]
+MGR_SOURCES = ["manager.cpp"]
+MGR_DEPS = MGR_SOURCES + ["../../include/madrona_mi355/manager.hpp",
+                          "../../include/madrona_mi355/types.hpp", "../../include/mrx.h"]
+PY_SOURCES = ["py_module.cpp", "manager.cpp"]
+
+
+def ext_suffix():
+    return sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+
+
+def lib_path():
+    return os.path.join(HERE, "libmrx_hip.so")
+
+
+def mgr_path():
+    return os.path.join(HERE, "libmadrona_mi355.so")
+
+
+def module_path():
+    return os.path.join(HERE, "madrona_renderer" + ext_suffix())
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    out = lib_path()
+    if force or _stale(out, HIP_DEPS):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+               "-shared", "-ffp-contract=off", "-fno-fast-math",
+               "-Wall", "-Wno-unused-function"]
+        cmd += list(extra_flags)
+        cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
+        cmd += ["-lz", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+        _run(cmd, verbose)
+    return out
+
+
+def build_manager(force=False, verbose=False):
+    out = mgr_path()
+    if force or _stale(out, MGR_DEPS) or \
+            os.path.getmtime(out) < os.path.getmtime(lib_path()):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+        cmd += [os.path.join(CSRC, s) for s in MGR_SOURCES]
+        cmd += ["-L" + HERE, "-lmrx_hip", "-Wl,-rpath,$ORIGIN", "-o", out]
+        _run(cmd, verbose)
+    return out
+
+
+def build_module(force=False, verbose=False):
+    import pybind11
+    out = module_path()
+    if force or _stale(out, PY_SOURCES + MGR_DEPS) or \
+            os.path.getmtime(out) < os.path.getmtime(lib_path()):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-fvisibility=hidden",
+               "-I" + pybind11.get_include(),
+               "-I" + sysconfig.get_paths()["include"]]
+        cmd += [os.path.join(CSRC, s) for s in PY_SOURCES]
+        cmd += ["-L" + HERE, "-lmrx_hip", "-Wl,-rpath,$ORIGIN", "-o", out]
+        _run(cmd, verbose)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_manager(force, verbose)
+    build_module(force, verbose)
+    return lib_path(), mgr_path(), module_path()
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))

@@ -1,0 +1,343 @@
+#include "assets.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <zlib.h>
+
+namespace mrx {
+
+namespace {
+
+bool readFile(const std::string &path, std::vector<uint8_t> &buf, std::string &err)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) {
+        err = "cannot open '" + path + "'";
+        return false;
+    }
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    buf.resize(sz > 0 ? (size_t)sz : 0);
+    size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    if (got != buf.size()) {
+        err = "short read on '" + path + "'";
+        return false;
+    }
+    return true;
+}
+
+// Text numbers go through strtod and one rounding to float, the same path a
+// Python float() -> numpy.float32 conversion takes.
+inline float parseFloat(const char *&p)
+{
+    char *end = nullptr;
+    double d = std::strtod(p, &end);
+    p = end;
+    return (float)d;
+}
+
+inline void skipSpace(const char *&p)
+{
+    while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
+}
+
+struct Corner {
+    int v;
+    int vt;  // -1: none
+};
+
+}  // namespace
+
+bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
+{
+    std::vector<uint8_t> file;
+    if (!readFile(path, file, err))
+        return false;
+    file.push_back('\n');
+    file.push_back(0);
+
+    std::vector<float> vs, vts;
+    std::vector<Corner> corners;
+    out.pos.clear();
+    out.uv.clear();
+
+    const char *p = (const char *)file.data();
+    int lineNo = 0;
+    while (*p) {
+        ++lineNo;
+        const char *eol = std::strchr(p, '\n');
+        skipSpace(p);
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            p += 1;
+            for (int i = 0; i < 3; ++i) {
+                skipSpace(p);
+                vs.push_back(parseFloat(p));
+            }
+        } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
+            p += 2;
+            for (int i = 0; i < 2; ++i) {
+                skipSpace(p);
+                vts.push_back(parseFloat(p));
+            }
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            p += 1;
+            corners.clear();
+            const int nv = (int)(vs.size() / 3), nt = (int)(vts.size() / 2);
+            while (true) {
+                skipSpace(p);
+                if (p >= eol || *p == '\n')
+                    break;
+                char *end = nullptr;
+                long vi = std::strtol(p, &end, 10);
+                if (end == p) {
+                    err = path + ": bad face at line " + std::to_string(lineNo);
+                    return false;
+                }
+                p = end;
+                Corner c;
+                c.v = vi > 0 ? (int)vi - 1 : nv + (int)vi;
+                c.vt = -1;
+                if (*p == '/') {
+                    ++p;
+                    if (*p != '/' ) {
+                        long ti = std::strtol(p, &end, 10);
+                        if (end != p) {
+                            c.vt = ti > 0 ? (int)ti - 1 : nt + (int)ti;
+                            p = end;
+                        }
+                    }
+                    if (*p == '/') {  // normal index: parsed and ignored
+                        ++p;
+                        std::strtol(p, &end, 10);
+                        p = end;
+                    }
+                }
+                if (c.v < 0 || c.v >= nv || c.vt >= nt) {
+                    err = path + ": index out of range at line " +
+                          std::to_string(lineNo);
+                    return false;
+                }
+                corners.push_back(c);
+            }
+            for (size_t j = 1; j + 1 < corners.size(); ++j) {
+                const Corner tri[3] = { corners[0], corners[j], corners[j + 1] };
+                for (const Corner &c : tri) {
+                    out.pos.push_back(vs[3 * c.v + 0]);
+                    out.pos.push_back(vs[3 * c.v + 1]);
+                    out.pos.push_back(vs[3 * c.v + 2]);
+                    out.uv.push_back(c.vt >= 0 ? vts[2 * c.vt + 0] : 0.0f);
+                    out.uv.push_back(c.vt >= 0 ? vts[2 * c.vt + 1] : 0.0f);
+                }
+            }
+        }
+        p = eol + 1;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// PNG: colour types 0/2/3/4/6, bit depths 1-16, non-interlaced.
+// ---------------------------------------------------------------------------
+namespace {
+
+inline uint32_t be32(const uint8_t *p)
+{
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) |
+           ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+inline int paeth(int a, int b, int c)
+{
+    int p = a + b - c;
+    int pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+}  // namespace
+
+bool decodePNGMem(const uint8_t *data, size_t size, Image &out, std::string &err)
+{
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    if (size < 8 || std::memcmp(data, sig, 8) != 0) {
+        err = "not a PNG";
+        return false;
+    }
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    size_t off = 8;
+    bool sawEnd = false;
+    while (off + 12 <= size && !sawEnd) {
+        uint32_t len = be32(data + off);
+        const uint8_t *type = data + off + 4;
+        const uint8_t *body = data + off + 8;
+        if (off + 12 + (size_t)len > size) {
+            err = "truncated PNG chunk";
+            return false;
+        }
+        if (!std::memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(body);
+            h = be32(body + 4);
+            depth = body[8];
+            ctype = body[9];
+            interlace = body[12];
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!std::memcmp(type, "tRNS", 4)) {
+            trns.assign(body, body + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            sawEnd = true;
+        }
+        off += 12 + (size_t)len;
+    }
+    if (w == 0 || h == 0 || ctype < 0) {
+        err = "PNG without IHDR";
+        return false;
+    }
+    if (interlace != 0) {
+        err = "interlaced PNG not supported";
+        return false;
+    }
+    int channels;
+    switch (ctype) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: err = "bad PNG colour type"; return false;
+    }
+    if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) ||
+        (ctype == 3 && depth == 16) ||
+        ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8)) {
+        err = "bad PNG bit depth";
+        return false;
+    }
+    const size_t bitsPerPixel = (size_t)channels * depth;
+    const size_t stride = ((size_t)w * bitsPerPixel + 7) / 8;
+    const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;
+
+    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    uLongf rawLen = (uLongf)raw.size();
+    int zr = uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size());
+    if (zr != Z_OK || rawLen != raw.size()) {
+        err = "PNG inflate failed";
+        return false;
+    }
+
+    // undo the scanline filters in place
+    std::vector<uint8_t> zero(stride, 0);
+    for (uint32_t y = 0; y < h; ++y) {
+        uint8_t *line = raw.data() + (size_t)y * (stride + 1);
+        const uint8_t ft = line[0];
+        uint8_t *cur = line + 1;
+        const uint8_t *up = y ? line - stride : zero.data();
+        for (size_t i = 0; i < stride; ++i) {
+            int a = i >= bpp ? cur[i - bpp] : 0;
+            int b = up[i];
+            int c = i >= bpp ? up[i - bpp] : 0;
+            int x = cur[i];
+            switch (ft) {
+            case 0: break;
+            case 1: x += a; break;
+            case 2: x += b; break;
+            case 3: x += (a + b) >> 1; break;
+            case 4: x += paeth(a, b, c); break;
+            default: err = "bad PNG filter"; return false;
+            }
+            cur[i] = (uint8_t)x;
+        }
+    }
+
+    out.width = w;
+    out.height = h;
+    out.rgba.assign((size_t)w * h * 4, 255);
+    const int maxv = (1 << (depth > 8 ? 8 : depth)) - 1;
+    auto sample = [&](const uint8_t *row, size_t idx) -> int {
+        // idx-th sample of the row, reduced to 8 bits for depth 16
+        if (depth == 8) return row[idx];
+        if (depth == 16) return row[2 * idx];
+        const size_t bit = idx * depth;
+        const int shift = 8 - depth - (int)(bit & 7);
+        return (row[bit >> 3] >> shift) & maxv;
+    };
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t *row = raw.data() + (size_t)y * (stride + 1) + 1;
+        uint8_t *dst = out.rgba.data() + (size_t)y * w * 4;
+        for (uint32_t x = 0; x < w; ++x, dst += 4) {
+            switch (ctype) {
+            case 0: {
+                int g = sample(row, x);
+                int g8 = depth < 8 ? g * 255 / maxv : g;
+                dst[0] = dst[1] = dst[2] = (uint8_t)g8;
+                if (trns.size() >= 2) {
+                    int key = depth == 16 ? trns[0] : trns[1];
+                    if (depth == 16 ? (row[2 * x] == trns[0] && row[2 * x + 1] == trns[1])
+                                    : g == key)
+                        dst[3] = 0;
+                }
+                break;
+            }
+            case 2: {
+                dst[0] = (uint8_t)sample(row, 3 * x + 0);
+                dst[1] = (uint8_t)sample(row, 3 * x + 1);
+                dst[2] = (uint8_t)sample(row, 3 * x + 2);
+                if (trns.size() >= 6) {
+                    bool hit;
+                    if (depth == 16)
+                        hit = !std::memcmp(row + 6 * x, trns.data(), 6);
+                    else
+                        hit = dst[0] == trns[1] && dst[1] == trns[3] && dst[2] == trns[5];
+                    if (hit) dst[3] = 0;
+                }
+                break;
+            }
+            case 3: {
+                size_t i = (size_t)sample(row, x);
+                if (3 * i + 2 < plte.size()) {
+                    dst[0] = plte[3 * i];
+                    dst[1] = plte[3 * i + 1];
+                    dst[2] = plte[3 * i + 2];
+                } else {
+                    dst[0] = dst[1] = dst[2] = 0;
+                }
+                if (i < trns.size()) dst[3] = trns[i];
+                break;
+            }
+            case 4: {
+                int g = sample(row, 2 * x);
+                dst[0] = dst[1] = dst[2] = (uint8_t)g;
+                dst[3] = (uint8_t)sample(row, 2 * x + 1);
+                break;
+            }
+            case 6: {
+                for (int c = 0; c < 4; ++c)
+                    dst[c] = (uint8_t)sample(row, 4 * x + c);
+                break;
+            }
+            }
+        }
+    }
+    return true;
+}
+
+bool decodePNG(const std::string &path, Image &out, std::string &err)
+{
+    std::vector<uint8_t> file;
+    if (!readFile(path, file, err))
+        return false;
+    if (!decodePNGMem(file.data(), file.size(), out, err)) {
+        err = path + ": " + err;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace mrx

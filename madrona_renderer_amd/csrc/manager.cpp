@@ -1,0 +1,166 @@
+// madRender::Manager over the C-ABI (include/mrx.h).  Mirrors the control
+// flow of the reference's Manager (/root/reference/src/mgr.cpp:505-665):
+// construct -> first frame rendered; step(); tensor getters that wrap device
+// pointers without copying.
+#include "../../include/madrona_mi355/manager.hpp"
+#include "../../include/mrx.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace madRender {
+
+namespace detail {
+static bool g_throwOnError = false;
+// The reference aborts on every error (FATAL / REQ_CUDA / assert:
+// mgr.cpp:306,320,420,595).  Language bindings flip this so the same
+// conditions surface as exceptions instead of killing the interpreter.
+void setThrowOnError(bool v) { g_throwOnError = v; }
+
+[[noreturn]] static void fatal(const std::string &msg)
+{
+    if (g_throwOnError)
+        throw std::runtime_error(msg);
+    std::fprintf(stderr, "FATAL: %s\n", msg.c_str());
+    std::fflush(stderr);
+    std::abort();
+}
+}  // namespace detail
+
+using madrona::py::Tensor;
+using madrona::py::TensorElementType;
+
+struct Manager::Impl {
+    mrx_renderer *r = nullptr;
+    ~Impl() { mrx_destroy(r); }
+
+    Tensor wrap(int which) const
+    {
+        int64_t dims[4] = { 0, 0, 0, 0 };
+        int ndim = 0, dtype = 0, dev = 0;
+        void *p = mrx_buffer(r, which, dims, &ndim, &dtype, &dev);
+        if (!p)
+            detail::fatal(mrx_last_error());
+        TensorElementType t = dtype == MRX_DTYPE_U8 ? TensorElementType::UInt8
+                            : dtype == MRX_DTYPE_I32 ? TensorElementType::Int32
+                                                     : TensorElementType::Float32;
+        return Tensor(p, t, dims, ndim, dev);
+    }
+};
+
+Manager::Manager(const Config &cfg)
+    : impl_(new Impl())
+{
+    static_assert(sizeof(mrx_instance) == sizeof(ImportedInstance), "instance ABI");
+    static_assert(sizeof(mrx_camera) == sizeof(ImportedCamera), "camera ABI");
+    static_assert(sizeof(mrx_world_init) == sizeof(Sim::WorldInit), "world ABI");
+    static_assert(sizeof(mrx_material) == sizeof(AdditionalMaterial), "material ABI");
+
+    mrx_config c {};
+    c.struct_size = sizeof(mrx_config);
+    c.gpu_id = cfg.gpuID;
+    c.num_worlds = cfg.numWorlds;
+    c.render_mode = cfg.renderMode == RenderMode::Raytracer ? MRX_MODE_RAYTRACER
+                                                            : MRX_MODE_RASTERIZER;
+    c.view_width = cfg.batchRenderViewWidth;
+    c.view_height = cfg.batchRenderViewHeight;
+    const Config::RenderConfig &rc = cfg.rcfg;
+    c.geo.vertices = reinterpret_cast<const float *>(rc.geoCfg.vertices);
+    c.geo.uvs = reinterpret_cast<const float *>(rc.geoCfg.uvs);
+    c.geo.indices = rc.geoCfg.indices;
+    c.geo.mesh_vertex_offsets = rc.geoCfg.meshVertexOffsets;
+    c.geo.mesh_index_offsets = rc.geoCfg.meshIndexOffsets;
+    c.geo.mesh_materials = rc.geoCfg.meshMaterials;
+    c.geo.num_vertices = rc.geoCfg.numVertices;
+    c.geo.num_indices = rc.geoCfg.numIndices;
+    c.geo.num_meshes = rc.geoCfg.numMeshes;
+    c.asset_paths = rc.assetPaths;
+    c.num_asset_paths = rc.numAssetPaths;
+    c.mat_assignments = rc.matAssignments;
+    c.num_mat_assignments = rc.numMatAssignments;
+    c.materials = reinterpret_cast<const mrx_material *>(rc.additionalMats);
+    c.num_materials = rc.numAdditionalMats;
+    c.texture_paths = rc.additionalTextures;
+    c.num_textures = rc.numAdditionalTextures;
+    c.instances = reinterpret_cast<const mrx_instance *>(rc.importedInstances);
+    c.num_instances = rc.numInstances;
+    c.cameras = reinterpret_cast<const mrx_camera *>(rc.cameras);
+    c.num_cameras = rc.numCameras;
+    c.worlds = reinterpret_cast<const mrx_world_init *>(rc.worlds);
+    c.stream = nullptr;
+    // build-only knobs travel by environment so Config stays field-compatible
+    if (const char *v = std::getenv("MADRONA_MI355_VISIBILITY"))
+        if (std::atoi(v) != 0)
+            c.flags |= MRX_FLAG_VISIBILITY_IDS;
+    if (const char *k = std::getenv("MADRONA_MI355_KERNEL"))
+        c.kernel_variant = std::atoi(k);
+
+    if (mrx_create(&c, &impl_->r) != MRX_OK)
+        detail::fatal(mrx_last_error());
+
+    // vestigial in the reference too (mgr.cpp:516-522)
+    const char *num_agents_str = std::getenv("HIDESEEK_NUM_AGENTS");
+    numAgents = num_agents_str ? (uint32_t)std::atoi(num_agents_str) : 1u;
+    // mrx_create already rendered the first frame (mgr.cpp:524)
+}
+
+Manager::~Manager() {}
+
+void Manager::step()
+{
+    if (mrx_step(impl_->r) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
+void Manager::render()
+{
+    if (mrx_render(impl_->r) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
+void Manager::sync()
+{
+    if (mrx_sync(impl_->r) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
+Tensor Manager::rgbTensor() const { return impl_->wrap(MRX_BUF_RGB); }
+Tensor Manager::depthTensor() const { return impl_->wrap(MRX_BUF_DEPTH); }
+Tensor Manager::segmaskTensor() const { return impl_->wrap(MRX_BUF_SEGMASK); }
+Tensor Manager::visibilityTensor() const { return impl_->wrap(MRX_BUF_VISIBILITY); }
+
+Tensor Manager::instancePositionTensor() const
+{
+    return impl_->wrap(MRX_BUF_INSTANCE_POSITION);
+}
+Tensor Manager::instanceRotationTensor() const
+{
+    return impl_->wrap(MRX_BUF_INSTANCE_ROTATION);
+}
+Tensor Manager::cameraPositionTensor() const
+{
+    return impl_->wrap(MRX_BUF_CAMERA_POSITION);
+}
+Tensor Manager::cameraRotationTensor() const
+{
+    return impl_->wrap(MRX_BUF_CAMERA_ROTATION);
+}
+
+uint64_t Manager::rgbCudaPtr() const { return (uint64_t)rgbTensor().devicePtr(); }
+uint64_t Manager::depthCudaPtr() const { return (uint64_t)depthTensor().devicePtr(); }
+uint64_t Manager::segmaskCudaPtr() const { return (uint64_t)segmaskTensor().devicePtr(); }
+
+float Manager::timeRenders(int steps)
+{
+    float ms = 0.f;
+    if (mrx_time_renders(impl_->r, steps, &ms) != MRX_OK)
+        detail::fatal(mrx_last_error());
+    return ms;
+}
+
+void *Manager::nativeHandle() const { return impl_->r; }
+
+}  // namespace madRender

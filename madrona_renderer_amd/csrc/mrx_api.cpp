@@ -1,0 +1,562 @@
+// C-ABI implementation (include/mrx.h): scene ingestion, world assembly,
+// device state and the per-frame launch.  HIP only -- no CPU rendering path.
+#include "../../include/mrx.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "assets.hpp"
+#include "raster.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define MRX_HIP(call)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return fail(MRX_E_HIP, std::string(#call) + ": " +                 \
+                                       hipGetErrorString(e_));                 \
+    } while (0)
+
+// Build-defined constants of the rendering spec.
+constexpr double kVfovDeg = 90.0;      // /root/reference/src/sim.cpp:170
+constexpr float kRasterZNear = 0.001f; // /root/reference/src/sim.cpp:170
+constexpr float kRtZNear = 0.1f;       // /root/reference/src/mgr.cpp:477
+constexpr float kRtZFar = 1000.f;      // /root/reference/src/mgr.cpp:478
+constexpr double kLightDir[3] = { 1.0, -1.0, -0.05 };  // mgr.cpp:357
+constexpr float kAmbient = 0.25f;
+constexpr float kDiffuse = 0.75f;
+
+template <typename T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t count = 0;
+    hipError_t alloc(size_t n)
+    {
+        count = n;
+        return hipMalloc((void **)&ptr, (n ? n : 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty())
+            return e;
+        return hipMemcpy(ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+    }
+};
+
+}  // namespace
+
+struct mrx_renderer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int32_t mode = MRX_MODE_RASTERIZER;
+    uint32_t flags = 0;
+    int32_t variant = 0;
+    uint64_t stepCount = 0;
+    mrx_info_t info {};
+    mrx::RasterParams params {};
+    // host copies kept for mrx_copy_triangles
+    std::vector<mrx::ObjTri> hostTris;
+    std::vector<int32_t> objFirst, objCount;
+    // device state
+    DevBuf<mrx::ObjTri> tris;
+    DevBuf<mrx::Material> materials;
+    DevBuf<mrx::TexDesc> textures;
+    DevBuf<uint32_t> texels;
+    DevBuf<mrx::WorldTri> worldTris;
+    DevBuf<uint32_t> worldTriStart, viewWorld;
+    DevBuf<float> instPos, instRot, instScale, camPos, camRot;
+    DevBuf<int32_t> instObj;
+    DevBuf<uint32_t> rgb;
+    DevBuf<float> depth;
+    DevBuf<int32_t> ids;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    ~mrx_renderer()
+    {
+        (void)hipSetDevice(device);
+        tris.release(); materials.release(); textures.release(); texels.release();
+        worldTris.release(); worldTriStart.release(); viewWorld.release();
+        instPos.release(); instRot.release(); instScale.release();
+        camPos.release(); camRot.release(); instObj.release();
+        rgb.release(); depth.release(); ids.release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+namespace {
+
+int buildScene(const mrx_config &cfg, mrx_renderer &r)
+{
+    using namespace mrx;
+    // ---- objects: disk assets in path order, then one object per raw mesh
+    //      (/root/reference/src/mgr.cpp:267-270, scripts/test.py:7-10)
+    std::vector<ObjTri> &tris = r.hostTris;
+    auto appendObject = [&](const float *pos, const float *uv, uint32_t n, int32_t mat) {
+        r.objFirst.push_back((int32_t)tris.size());
+        r.objCount.push_back((int32_t)n);
+        for (uint32_t t = 0; t < n; ++t) {
+            ObjTri o {};
+            std::memcpy(o.p, pos + 9 * (size_t)t, sizeof(o.p));
+            std::memcpy(o.uv, uv + 6 * (size_t)t, sizeof(o.uv));
+            o.mat = mat;
+            tris.push_back(o);
+        }
+    };
+    for (uint32_t a = 0; a < cfg.num_asset_paths; ++a) {
+        TriSoup soup;
+        std::string err;
+        if (!loadOBJ(cfg.asset_paths[a], soup, err))
+            return fail(MRX_E_ASSET, "Failed to load render assets: " + err);
+        // The reference carries a per-asset material id through its API
+        // (bindings.cpp:26-36) but applies it only inside a disabled block
+        // (mgr.cpp:339-349); the block's evident intent is implemented here:
+        // mat_id indexes the additional materials, -1 leaves the default.
+        int32_t mat = -1;
+        if (cfg.mat_assignments && a < cfg.num_mat_assignments)
+            mat = cfg.mat_assignments[a];
+        appendObject(soup.pos.data(), soup.uv.data(), soup.numTris(), mat);
+    }
+    const mrx_geometry &g = cfg.geo;
+    for (uint32_t m = 0; m < g.num_meshes; ++m) {   // mgr.cpp:214-272
+        const uint32_t v0 = g.mesh_vertex_offsets[m];
+        const uint32_t v1 = m + 1 < g.num_meshes ? g.mesh_vertex_offsets[m + 1] : g.num_vertices;
+        const uint32_t i0 = g.mesh_index_offsets[m];
+        const uint32_t i1 = m + 1 < g.num_meshes ? g.mesh_index_offsets[m + 1] : g.num_indices;
+        if (v1 < v0 || v1 > g.num_vertices || i1 < i0 || i1 > g.num_indices)
+            return fail(MRX_E_INVALID, "raw mesh offsets out of range");
+        const uint32_t nt = (i1 - i0) / 3;
+        std::vector<float> pos(9 * (size_t)nt), uv(6 * (size_t)nt);
+        for (uint32_t t = 0; t < nt; ++t)
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t vi = g.indices[i0 + 3 * t + c];
+                if (vi >= v1 - v0)
+                    return fail(MRX_E_INVALID, "raw mesh index out of range");
+                std::memcpy(&pos[9 * (size_t)t + 3 * c], g.vertices + 3 * (size_t)(v0 + vi), 12);
+                std::memcpy(&uv[6 * (size_t)t + 2 * c], g.uvs + 2 * (size_t)(v0 + vi), 8);
+            }
+        appendObject(pos.data(), uv.data(), nt, g.mesh_materials[m]);
+    }
+
+    // ---- textures and materials (mgr.cpp:316-337; no disk textures or
+    //      materials exist, so the index shift there is zero)
+    std::vector<TexDesc> texDescs;
+    std::vector<uint32_t> texels;
+    for (uint32_t t = 0; t < cfg.num_textures; ++t) {
+        Image img;
+        std::string err;
+        if (!decodePNG(cfg.texture_paths[t], img, err))
+            return fail(MRX_E_ASSET, "Failed to load texture: " + err);
+        TexDesc d {};
+        d.offset = (uint32_t)texels.size();
+        d.width = img.width;
+        d.height = img.height;
+        texDescs.push_back(d);
+        const size_t n = (size_t)img.width * img.height;
+        texels.resize(texels.size() + n);
+        std::memcpy(texels.data() + d.offset, img.rgba.data(), n * 4);
+    }
+    std::vector<Material> mats(cfg.num_materials);
+    for (uint32_t m = 0; m < cfg.num_materials; ++m) {
+        std::memcpy(mats[m].color, cfg.materials[m].color, 16);
+        mats[m].tex = cfg.materials[m].texture_idx;
+    }
+
+    // ---- world assembly: per-world copies of the table rows, world-major
+    //      (/root/reference/src/sim.cpp:143-175)
+    std::vector<float> instPos, instRot, instScale, camPos, camRot;
+    std::vector<int32_t> instObj;
+    std::vector<uint32_t> worldTriStart(1, 0), viewWorld;
+    std::vector<WorldTri> worldTris;
+    uint32_t maxWorldTris = 0;
+    for (uint32_t w = 0; w < cfg.num_worlds; ++w) {
+        const mrx_world_init &wi = cfg.worlds[w];
+        if ((uint64_t)wi.instances_offset + wi.num_instances > cfg.num_instances ||
+            (uint64_t)wi.cameras_offset + wi.num_cameras > cfg.num_cameras)
+            return fail(MRX_E_INVALID, "world " + std::to_string(w) +
+                                           " addresses rows outside the tables");
+        for (uint32_t i = 0; i < wi.num_instances; ++i) {
+            const mrx_instance &in = cfg.instances[wi.instances_offset + i];
+            const uint32_t row = (uint32_t)instObj.size();
+            instPos.insert(instPos.end(), in.position, in.position + 3);
+            instRot.insert(instRot.end(), in.rotation, in.rotation + 4);
+            instScale.insert(instScale.end(), in.scale, in.scale + 3);
+            instObj.push_back(in.object_id);
+            if (in.object_id >= 0 && (size_t)in.object_id < r.objFirst.size()) {
+                const uint32_t f = (uint32_t)r.objFirst[in.object_id];
+                const uint32_t n = (uint32_t)r.objCount[in.object_id];
+                for (uint32_t t = 0; t < n; ++t)
+                    worldTris.push_back(WorldTri { row, f + t });
+            }
+        }
+        worldTriStart.push_back((uint32_t)worldTris.size());
+        const uint32_t nt = worldTriStart[w + 1] - worldTriStart[w];
+        maxWorldTris = nt > maxWorldTris ? nt : maxWorldTris;
+        for (uint32_t c = 0; c < wi.num_cameras; ++c) {
+            const mrx_camera &cam = cfg.cameras[wi.cameras_offset + c];
+            camPos.insert(camPos.end(), cam.position, cam.position + 3);
+            camRot.insert(camRot.end(), cam.rotation, cam.rotation + 4);
+            viewWorld.push_back(w);
+        }
+    }
+
+    // ---- upload
+    MRX_HIP(r.tris.upload(tris));
+    MRX_HIP(r.materials.upload(mats));
+    MRX_HIP(r.textures.upload(texDescs));
+    MRX_HIP(r.texels.upload(texels));
+    MRX_HIP(r.worldTris.upload(worldTris));
+    MRX_HIP(r.worldTriStart.upload(worldTriStart));
+    MRX_HIP(r.viewWorld.upload(viewWorld));
+    MRX_HIP(r.instPos.upload(instPos));
+    MRX_HIP(r.instRot.upload(instRot));
+    MRX_HIP(r.instScale.upload(instScale));
+    MRX_HIP(r.instObj.upload(instObj));
+    MRX_HIP(r.camPos.upload(camPos));
+    MRX_HIP(r.camRot.upload(camRot));
+
+    const bool rt = cfg.render_mode == MRX_MODE_RAYTRACER;
+    const uint32_t W = cfg.view_width;
+    // Raytracer output is square, res = view width (mgr.cpp:130,443)
+    const uint32_t H = rt ? cfg.view_width : cfg.view_height;
+    const uint32_t nviews = (uint32_t)viewWorld.size();
+    // storage [view][slow][fast]: raster fast = image x; Raytracer fast =
+    // image y (callers read it as [x][y]: scripts/test.py:160, dump.cpp:9-21)
+    const uint32_t nfast = rt ? H : W, nslow = rt ? W : H;
+    const size_t px = (size_t)nviews * nfast * nslow;
+    MRX_HIP(r.rgb.alloc(px));
+    MRX_HIP(r.depth.alloc(px));
+    const bool wantIds = rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS);
+    if (wantIds)
+        MRX_HIP(r.ids.alloc(px));
+
+    RasterParams &p = r.params;
+    p.tris = r.tris.ptr;
+    p.materials = r.materials.ptr;
+    p.textures = r.textures.ptr;
+    p.texels = r.texels.ptr;
+    p.numMaterials = (uint32_t)mats.size();
+    p.numTextures = (uint32_t)texDescs.size();
+    p.worldTris = r.worldTris.ptr;
+    p.worldTriStart = r.worldTriStart.ptr;
+    p.viewWorld = r.viewWorld.ptr;
+    p.instPos = r.instPos.ptr;
+    p.instRot = r.instRot.ptr;
+    p.instScale = r.instScale.ptr;
+    p.instObj = r.instObj.ptr;
+    p.camPos = r.camPos.ptr;
+    p.camRot = r.camRot.ptr;
+    p.rgb = r.rgb.ptr;
+    p.depth = r.depth.ptr;
+    p.ids = wantIds ? r.ids.ptr : nullptr;
+    p.numViews = nviews;
+    p.nfast = nfast;
+    p.nslow = nslow;
+    p.tilesFast = (nfast + 63) / 64;
+    p.tilesSlow = (nslow + 63) / 64;
+    // S5: pixel -> ray constants, double math rounded once to float
+    const float th = (float)std::tan(kVfovDeg * M_PI / 360.0);
+    const double asp = (double)W / (double)H;
+    p.sx = (float)(2.0 * (double)th * asp / (double)W);
+    p.ox = (float)((1.0 / (double)W - 1.0) * (double)th * asp);
+    p.sz = (float)(-2.0 * (double)th / (double)H);
+    p.oz = (float)((1.0 - 1.0 / (double)H) * (double)th);
+    p.invNear = 1.0f / (rt ? kRtZNear : kRasterZNear);
+    p.invFar = rt ? 1.0f / kRtZFar : 0.0f;
+    const double ln = std::sqrt(kLightDir[0] * kLightDir[0] + kLightDir[1] * kLightDir[1] +
+                                kLightDir[2] * kLightDir[2]);
+    for (int c = 0; c < 3; ++c)
+        p.toLight[c] = (float)(-kLightDir[c] / ln);
+    p.ambient = kAmbient;
+    p.diffuse = kDiffuse;
+    p.defaultColor[0] = p.defaultColor[1] = p.defaultColor[2] = p.defaultColor[3] = 1.0f;
+    p.transposed = rt ? 1 : 0;
+    // Raytracer ids are the segmask unless the caller asked for visibility ids
+    p.idsAreSegmask = (rt && !(cfg.flags & MRX_FLAG_VISIBILITY_IDS)) ? 1 : 0;
+
+    mrx_info_t &inf = r.info;
+    inf.num_worlds = cfg.num_worlds;
+    inf.num_views = nviews;
+    inf.num_instances = (uint32_t)instObj.size();
+    inf.num_objects = (uint32_t)r.objFirst.size();
+    inf.num_triangles = (uint32_t)tris.size();
+    inf.num_materials = (uint32_t)mats.size();
+    inf.num_textures = (uint32_t)texDescs.size();
+    inf.max_world_triangles = maxWorldTris;
+    inf.storage_fast = nfast;
+    inf.storage_slow = nslow;
+    inf.device_id = r.device;
+    inf.kernel_variant = r.variant;
+    inf.bytes_per_step = (uint64_t)px * (wantIds ? 12u : 8u) +
+                         44ull * inf.num_instances + 28ull * nviews;
+    return MRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrx_abi_version(void) { return MRX_ABI_VERSION; }
+
+const char *mrx_last_error(void) { return g_err.c_str(); }
+
+int mrx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int mrx_create(const mrx_config *cfg, mrx_renderer **out)
+{
+    if (!cfg || !out)
+        return fail(MRX_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(mrx_config))
+        return fail(MRX_E_INVALID, "mrx_config size mismatch (ABI)");
+    if (cfg->render_mode != MRX_MODE_RASTERIZER && cfg->render_mode != MRX_MODE_RAYTRACER)
+        return fail(MRX_E_INVALID, "bad render_mode");
+    if (cfg->view_width == 0 || cfg->view_height == 0 || cfg->view_width > 16384 ||
+        cfg->view_height > 16384)
+        return fail(MRX_E_INVALID, "bad view size");
+    if (cfg->num_worlds && !cfg->worlds)
+        return fail(MRX_E_INVALID, "worlds is null");
+    if (cfg->kernel_variant < 0 || cfg->kernel_variant >= mrx::kNumVariants)
+        return fail(MRX_E_INVALID, "bad kernel_variant");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MRX_E_NO_DEVICE,
+                    "no HIP device: this library renders on MI355X only (no CPU path)");
+    if (cfg->gpu_id < 0 || cfg->gpu_id >= ndev)
+        return fail(MRX_E_NO_DEVICE, "gpu_id " + std::to_string(cfg->gpu_id) +
+                                         " out of range (" + std::to_string(ndev) + " devices)");
+    MRX_HIP(hipSetDevice(cfg->gpu_id));
+
+    mrx_renderer *r = new mrx_renderer();
+    r->device = cfg->gpu_id;
+    r->stream = (hipStream_t)cfg->stream;
+    r->mode = cfg->render_mode;
+    r->flags = cfg->flags;
+    r->variant = cfg->kernel_variant;
+    int rc = buildScene(*cfg, *r);
+    if (rc == MRX_OK) {
+        hipError_t e = hipEventCreate(&r->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&r->ev1);
+        if (e != hipSuccess)
+            rc = fail(MRX_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    }
+    // the reference renders the first frame inside the constructor (mgr.cpp:524)
+    if (rc == MRX_OK)
+        rc = mrx_step(r);
+    if (rc == MRX_OK)
+        rc = mrx_sync(r);
+    if (rc != MRX_OK) {
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return MRX_OK;
+}
+
+void mrx_destroy(mrx_renderer *r)
+{
+    if (!r)
+        return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->stream);
+    delete r;
+}
+
+int mrx_render(mrx_renderer *r)
+{
+    if (!r)
+        return fail(MRX_E_INVALID, "null renderer");
+    MRX_HIP(hipSetDevice(r->device));
+    MRX_HIP(mrx::launchRaster(r->params, r->info.max_world_triangles, r->variant, r->stream));
+    return MRX_OK;
+}
+
+int mrx_step(mrx_renderer *r)
+{
+    // Manager::step = Step graph + Render graphs (mgr.cpp:177-185).  The Step
+    // graph only advances a per-world clock nothing reads (sim.cpp:73-77) and
+    // re-sorts static entities; what remains observable is the render.
+    if (!r)
+        return fail(MRX_E_INVALID, "null renderer");
+    r->stepCount++;
+    return mrx_render(r);
+}
+
+int mrx_sync(mrx_renderer *r)
+{
+    if (!r)
+        return fail(MRX_E_INVALID, "null renderer");
+    MRX_HIP(hipSetDevice(r->device));
+    MRX_HIP(hipStreamSynchronize(r->stream));
+    return MRX_OK;
+}
+
+void *mrx_stream(mrx_renderer *r) { return r ? (void *)r->stream : nullptr; }
+
+void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dtype,
+                 int *device)
+{
+    if (!r || !dims || !ndim || !dtype) {
+        fail(MRX_E_INVALID, "null argument");
+        return nullptr;
+    }
+    const bool rt = r->mode == MRX_MODE_RAYTRACER;
+    const int64_t V = r->info.num_views, I = r->info.num_instances;
+    const int64_t S = r->info.storage_slow, F = r->info.storage_fast;
+    void *ptr = nullptr;
+    if (device)
+        *device = r->device;
+    switch (which) {
+    case MRX_BUF_RGB:       // mgr.cpp:547-568
+        dims[0] = V; dims[1] = S; dims[2] = F; dims[3] = 4;
+        *ndim = 4; *dtype = MRX_DTYPE_U8; ptr = r->rgb.ptr;
+        break;
+    case MRX_BUF_DEPTH:     // mgr.cpp:570-590
+        dims[0] = V; dims[1] = S; dims[2] = F; dims[3] = 1;
+        *ndim = rt ? 3 : 4; *dtype = MRX_DTYPE_F32; ptr = r->depth.ptr;
+        break;
+    case MRX_BUF_SEGMASK:   // mgr.cpp:592-605
+        if (!rt) {
+            fail(MRX_E_UNSUPPORTED, "Segmask not implemented for rasterizer");
+            return nullptr;
+        }
+        if (!r->params.idsAreSegmask) {
+            fail(MRX_E_UNSUPPORTED, "ids buffer holds visibility ids (MRX_FLAG_VISIBILITY_IDS)");
+            return nullptr;
+        }
+        dims[0] = V; dims[1] = S; dims[2] = F;
+        *ndim = 3; *dtype = MRX_DTYPE_I32; ptr = r->ids.ptr;
+        break;
+    case MRX_BUF_VISIBILITY:
+        if (!r->ids.ptr || r->params.idsAreSegmask) {
+            fail(MRX_E_UNSUPPORTED, "visibility ids need MRX_FLAG_VISIBILITY_IDS");
+            return nullptr;
+        }
+        dims[0] = V; dims[1] = S; dims[2] = F;
+        *ndim = 3; *dtype = MRX_DTYPE_I32; ptr = r->ids.ptr;
+        break;
+    case MRX_BUF_INSTANCE_POSITION:   // mgr.cpp:627-635
+        dims[0] = I; dims[1] = 3; *ndim = 2; *dtype = MRX_DTYPE_F32; ptr = r->instPos.ptr;
+        break;
+    case MRX_BUF_INSTANCE_ROTATION:   // mgr.cpp:637-645
+        dims[0] = I; dims[1] = 4; *ndim = 2; *dtype = MRX_DTYPE_F32; ptr = r->instRot.ptr;
+        break;
+    case MRX_BUF_INSTANCE_SCALE:
+        dims[0] = I; dims[1] = 3; *ndim = 2; *dtype = MRX_DTYPE_F32; ptr = r->instScale.ptr;
+        break;
+    // The reference sizes the camera tensors with totalNumInstances
+    // (mgr.cpp:652,662); the rows that exist are one per camera, exported so.
+    case MRX_BUF_CAMERA_POSITION:
+        dims[0] = V; dims[1] = 3; *ndim = 2; *dtype = MRX_DTYPE_F32; ptr = r->camPos.ptr;
+        break;
+    case MRX_BUF_CAMERA_ROTATION:
+        dims[0] = V; dims[1] = 4; *ndim = 2; *dtype = MRX_DTYPE_F32; ptr = r->camRot.ptr;
+        break;
+    default:
+        fail(MRX_E_INVALID, "unknown buffer id");
+        return nullptr;
+    }
+    return ptr;
+}
+
+int mrx_info(mrx_renderer *r, mrx_info_t *out)
+{
+    if (!r || !out)
+        return fail(MRX_E_INVALID, "null argument");
+    *out = r->info;
+    return MRX_OK;
+}
+
+int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
+{
+    if (!r || !ms_total || steps < 0)
+        return fail(MRX_E_INVALID, "bad argument");
+    MRX_HIP(hipSetDevice(r->device));
+    MRX_HIP(hipEventRecord(r->ev0, r->stream));
+    for (int i = 0; i < steps; ++i)
+        MRX_HIP(mrx::launchRaster(r->params, r->info.max_world_triangles, r->variant, r->stream));
+    MRX_HIP(hipEventRecord(r->ev1, r->stream));
+    MRX_HIP(hipEventSynchronize(r->ev1));
+    MRX_HIP(hipEventElapsedTime(ms_total, r->ev0, r->ev1));
+    return MRX_OK;
+}
+
+int mrx_copy_triangles(mrx_renderer *r, float *tri_pos, float *tri_uv, int32_t *tri_mat,
+                       int32_t *obj_first, int32_t *obj_count)
+{
+    if (!r)
+        return fail(MRX_E_INVALID, "null renderer");
+    for (size_t t = 0; t < r->hostTris.size(); ++t) {
+        if (tri_pos) std::memcpy(tri_pos + 9 * t, r->hostTris[t].p, 36);
+        if (tri_uv) std::memcpy(tri_uv + 6 * t, r->hostTris[t].uv, 24);
+        if (tri_mat) tri_mat[t] = r->hostTris[t].mat;
+    }
+    for (size_t o = 0; o < r->objFirst.size(); ++o) {
+        if (obj_first) obj_first[o] = r->objFirst[o];
+        if (obj_count) obj_count[o] = r->objCount[o];
+    }
+    return MRX_OK;
+}
+
+int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv, uint32_t *num_tris)
+{
+    if (!path || !tri_pos || !tri_uv || !num_tris)
+        return fail(MRX_E_INVALID, "null argument");
+    mrx::TriSoup soup;
+    std::string err;
+    if (!mrx::loadOBJ(path, soup, err))
+        return fail(MRX_E_ASSET, err);
+    *num_tris = soup.numTris();
+    *tri_pos = (float *)std::malloc(soup.pos.size() * sizeof(float) + 4);
+    *tri_uv = (float *)std::malloc(soup.uv.size() * sizeof(float) + 4);
+    std::memcpy(*tri_pos, soup.pos.data(), soup.pos.size() * sizeof(float));
+    std::memcpy(*tri_uv, soup.uv.data(), soup.uv.size() * sizeof(float));
+    return MRX_OK;
+}
+
+int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width, uint32_t *height)
+{
+    if (!path || !rgba || !width || !height)
+        return fail(MRX_E_INVALID, "null argument");
+    mrx::Image img;
+    std::string err;
+    if (!mrx::decodePNG(path, img, err))
+        return fail(MRX_E_ASSET, err);
+    *width = img.width;
+    *height = img.height;
+    *rgba = (uint8_t *)std::malloc(img.rgba.size() + 4);
+    std::memcpy(*rgba, img.rgba.data(), img.rgba.size());
+    return MRX_OK;
+}
+
+void mrx_free(void *p) { std::free(p); }
+
+}  // extern "C"

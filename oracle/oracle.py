@@ -1,0 +1,329 @@
+"""ctypes front-end of the CPU oracle (oracle/raster_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of raster_oracle.c.  Imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package.  PARITY UNPINNED (the reference ships no arithmetic, tests or
+fixtures for this path: SURVEY.md section 8c); pinned instead by the anchors of
+tests/test_oracle_anchors.py.
+
+The scene description it consumes is any object with the attributes of the
+reference's ``MadronaRenderer(...)`` keyword arguments
+(/root/reference/src/bindings.cpp:206-222): ``asset_paths`` [(path, mat_id)],
+``mesh_vertices`` ... ``mesh_materials``, ``materials`` [(rgba, texture_id,
+roughness, metalness)], ``texture_paths``, ``instances`` [(pos, rot, scale,
+object_id)], ``cameras`` [(pos, rot)], ``worlds`` [(num_instances,
+instance_offset, num_cameras, camera_offset)], ``render_mode`` ("Rasterizer" |
+"Raytracer"), ``width``, ``height``.
+
+Asset ingestion here is deliberately a second, independent implementation
+(pure Python OBJ reader, Pillow PNG decode) of what the product does in C++
+(madrona_renderer_amd/csrc/assets.cpp), so the parity tests also cross-check
+the loaders.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# Build-defined constants of the rendering spec.
+VFOV_DEG = 90.0          # /root/reference/src/sim.cpp:170
+RASTER_ZNEAR = 0.001     # /root/reference/src/sim.cpp:170
+RT_ZNEAR = 0.1           # /root/reference/src/mgr.cpp:477
+RT_ZFAR = 1000.0         # /root/reference/src/mgr.cpp:478
+LIGHT_DIR = (1.0, -1.0, -0.05)   # /root/reference/src/mgr.cpp:357
+AMBIENT = 0.25
+DIFFUSE = 0.75
+DEFAULT_COLOR = (1.0, 1.0, 1.0, 1.0)
+
+
+class _Scene(ctypes.Structure):
+    _fields_ = [
+        ("tri_pos", ctypes.c_void_p), ("tri_uv", ctypes.c_void_p),
+        ("tri_mat", ctypes.c_void_p), ("obj_first_tri", ctypes.c_void_p),
+        ("obj_num_tris", ctypes.c_void_p), ("num_objects", ctypes.c_int32),
+        ("mat_color", ctypes.c_void_p), ("mat_tex", ctypes.c_void_p),
+        ("num_materials", ctypes.c_int32),
+        ("tex_data", ctypes.c_void_p), ("tex_offset", ctypes.c_void_p),
+        ("tex_w", ctypes.c_void_p), ("tex_h", ctypes.c_void_p),
+        ("num_textures", ctypes.c_int32),
+        ("inst_pos", ctypes.c_void_p), ("inst_rot", ctypes.c_void_p),
+        ("inst_scale", ctypes.c_void_p), ("inst_obj", ctypes.c_void_p),
+        ("world_inst_start", ctypes.c_void_p),
+        ("cam_pos", ctypes.c_void_p), ("cam_rot", ctypes.c_void_p),
+        ("view_world", ctypes.c_void_p), ("num_views", ctypes.c_int32),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("sx", ctypes.c_float), ("ox", ctypes.c_float),
+        ("sz", ctypes.c_float), ("oz", ctypes.c_float),
+        ("inv_near", ctypes.c_float), ("inv_far", ctypes.c_float),
+        ("to_light", ctypes.c_float * 3),
+        ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
+        ("default_color", ctypes.c_float * 4),
+        ("transposed", ctypes.c_int32),
+    ]
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "raster_oracle.c")
+    if force or not os.path.exists(so) or \
+            os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_render.restype = ctypes.c_int
+        _LIB.orc_render.argtypes = [ctypes.POINTER(_Scene), ctypes.c_int,
+                                    ctypes.c_int] + [ctypes.c_void_p] * 4 + \
+                                   [ctypes.c_int]
+        _LIB.orc_num_procs.restype = ctypes.c_int
+    return _LIB
+
+
+# --------------------------------------------------------------------------
+# independent asset readers
+# --------------------------------------------------------------------------
+def parse_obj(path):
+    """Wavefront OBJ -> (tri_pos [T,3,3] f32, tri_uv [T,3,2] f32).
+
+    One object per file; polygons fan-triangulated; ``vt`` optional."""
+    vs, vts, tris_p, tris_t = [], [], [], []
+    with open(path, "r") as f:
+        for line in f:
+            parts = line.split()
+            if not parts:
+                continue
+            if parts[0] == "v":
+                vs.append([float(x) for x in parts[1:4]])
+            elif parts[0] == "vt":
+                vts.append([float(x) for x in parts[1:3]])
+            elif parts[0] == "f":
+                corners = []
+                for c in parts[1:]:
+                    fields = c.split("/")
+                    vi = int(fields[0])
+                    vi = vi - 1 if vi > 0 else len(vs) + vi
+                    ti = None
+                    if len(fields) > 1 and fields[1] != "":
+                        ti = int(fields[1])
+                        ti = ti - 1 if ti > 0 else len(vts) + ti
+                    corners.append((vi, ti))
+                for j in range(1, len(corners) - 1):
+                    tri = (corners[0], corners[j], corners[j + 1])
+                    tris_p.append([vs[c[0]] for c in tri])
+                    tris_t.append([vts[c[1]] if c[1] is not None else [0.0, 0.0]
+                                   for c in tri])
+    pos = np.asarray(tris_p, dtype=np.float64).astype(np.float32).reshape(-1, 3, 3)
+    uv = np.asarray(tris_t, dtype=np.float64).astype(np.float32).reshape(-1, 3, 2)
+    return pos, uv
+
+
+def decode_image(path):
+    """Image file -> RGBA8 array [h, w, 4] (Pillow)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGBA"), dtype=np.uint8).copy()
+
+
+# --------------------------------------------------------------------------
+# scene flattening (mirrors /root/reference/src/mgr.cpp:214-363 ordering and
+# /root/reference/src/sim.cpp:135-176 world assembly)
+# --------------------------------------------------------------------------
+def _f32(x):
+    return np.float32(x)
+
+
+def projection_constants(width, height, transposed):
+    th = float(np.float32(math.tan(VFOV_DEG * math.pi / 360.0)))
+    asp = float(width) / float(height)
+    sx = np.float32(2.0 * th * asp / width)
+    ox = np.float32((1.0 / width - 1.0) * th * asp)
+    sz = np.float32(-2.0 * th / height)
+    oz = np.float32((1.0 - 1.0 / height) * th)
+    return sx, ox, sz, oz
+
+
+def to_light_vector():
+    d = np.asarray(LIGHT_DIR, dtype=np.float64)
+    return (-d / math.sqrt(float(d @ d))).astype(np.float32)
+
+
+class FlatScene:
+    """Flattened arrays in the layout raster_oracle.c reads."""
+
+    def __init__(self, desc, base_dir=None):
+        mode = getattr(desc, "render_mode", "Rasterizer")
+        mode = getattr(mode, "name", mode)
+        self.raytracer = (str(mode) == "Raytracer")
+        self.width = int(desc.width)
+        self.height = int(desc.height)
+        if self.raytracer:
+            # /root/reference/src/mgr.cpp:443 -- square, res = view width
+            self.height = self.width
+
+        def _path(p):
+            return p if (base_dir is None or os.path.isabs(p)) \
+                else os.path.join(base_dir, p)
+
+        # -- objects: disk assets first, then one object per raw mesh
+        pos_l, uv_l, mat_l, first, count = [], [], [], [], []
+        ntri = 0
+        for path, mat_id in desc.asset_paths:
+            p, t = parse_obj(_path(path))
+            pos_l.append(p)
+            uv_l.append(t)
+            # intended semantics of the disabled block mgr.cpp:339-349:
+            # mat_id indexes the additional materials (no disk materials).
+            mat_l.append(np.full(len(p), int(mat_id), dtype=np.int32))
+            first.append(ntri)
+            count.append(len(p))
+            ntri += len(p)
+        verts = np.asarray(desc.mesh_vertices, dtype=np.float32).reshape(-1, 3)
+        uvs = np.asarray(desc.mesh_uvs, dtype=np.float32).reshape(-1, 2)
+        idx = np.asarray(desc.mesh_indices, dtype=np.uint32).reshape(-1)
+        voff = np.asarray(desc.mesh_vertex_offsets, dtype=np.uint32).reshape(-1)
+        ioff = np.asarray(desc.mesh_indices_offsets, dtype=np.uint32).reshape(-1)
+        mmat = np.asarray(desc.mesh_materials, dtype=np.int32).reshape(-1)
+        for m in range(len(voff)):
+            v0 = int(voff[m])
+            v1 = int(voff[m + 1]) if m + 1 < len(voff) else len(verts)
+            i0 = int(ioff[m])
+            i1 = int(ioff[m + 1]) if m + 1 < len(ioff) else len(idx)
+            nt = (i1 - i0) // 3
+            ii = idx[i0:i0 + 3 * nt].astype(np.int64).reshape(-1, 3)
+            mv, mu = verts[v0:v1], uvs[v0:v1]
+            pos_l.append(mv[ii].reshape(-1, 3, 3))
+            uv_l.append(mu[ii].reshape(-1, 3, 2))
+            mat_l.append(np.full(nt, int(mmat[m]), dtype=np.int32))
+            first.append(ntri)
+            count.append(nt)
+            ntri += nt
+        self.tri_pos = np.ascontiguousarray(
+            np.concatenate(pos_l) if pos_l else np.zeros((0, 3, 3)), np.float32)
+        self.tri_uv = np.ascontiguousarray(
+            np.concatenate(uv_l) if uv_l else np.zeros((0, 3, 2)), np.float32)
+        self.tri_mat = np.ascontiguousarray(
+            np.concatenate(mat_l) if mat_l else np.zeros(0), np.int32)
+        self.obj_first_tri = np.asarray(first, dtype=np.int32)
+        self.obj_num_tris = np.asarray(count, dtype=np.int32)
+
+        # -- materials / textures
+        mats = list(desc.materials)
+        self.mat_color = np.asarray([m[0] for m in mats],
+                                    dtype=np.float32).reshape(-1, 4)
+        self.mat_tex = np.asarray([m[1] for m in mats], dtype=np.int32)
+        texels, offs, tw, th = [], [], [], []
+        o = 0
+        for p in desc.texture_paths:
+            img = decode_image(_path(p))
+            offs.append(o)
+            th.append(img.shape[0])
+            tw.append(img.shape[1])
+            texels.append(img.reshape(-1, 4))
+            o += img.shape[0] * img.shape[1]
+        self.tex_data = np.ascontiguousarray(
+            np.concatenate(texels) if texels else np.zeros((1, 4)), np.uint8)
+        self.tex_offset = np.asarray(offs if offs else [0], dtype=np.int64)
+        self.tex_w = np.asarray(tw if tw else [0], dtype=np.int32)
+        self.tex_h = np.asarray(th if th else [0], dtype=np.int32)
+        self.num_textures = len(texels)
+
+        # -- world assembly: per-world copies, world-major
+        inst = list(desc.instances)
+        cams = list(desc.cameras)
+        ipos, irot, iscl, iobj, wstart = [], [], [], [], [0]
+        cpos, crot, vworld = [], [], []
+        for w, (ni, io, nc, co) in enumerate(desc.worlds):
+            for r in inst[io:io + ni]:
+                ipos.append(r[0]); irot.append(r[1]); iscl.append(r[2])
+                iobj.append(r[3])
+            wstart.append(len(ipos))
+            for r in cams[co:co + nc]:
+                cpos.append(r[0]); crot.append(r[1]); vworld.append(w)
+        self.inst_pos = np.asarray(ipos, dtype=np.float32).reshape(-1, 3)
+        self.inst_rot = np.asarray(irot, dtype=np.float32).reshape(-1, 4)
+        self.inst_scale = np.asarray(iscl, dtype=np.float32).reshape(-1, 3)
+        self.inst_obj = np.asarray(iobj, dtype=np.int32)
+        self.world_inst_start = np.asarray(wstart, dtype=np.int32)
+        self.cam_pos = np.asarray(cpos, dtype=np.float32).reshape(-1, 3)
+        self.cam_rot = np.asarray(crot, dtype=np.float32).reshape(-1, 4)
+        self.view_world = np.asarray(vworld, dtype=np.int32)
+        self.num_views = len(vworld)
+
+    def _struct(self):
+        s = _Scene()
+        keep = []
+
+        def ptr(a):
+            keep.append(a)
+            return a.ctypes.data if a.size else None
+        s.tri_pos = ptr(self.tri_pos); s.tri_uv = ptr(self.tri_uv)
+        s.tri_mat = ptr(self.tri_mat)
+        s.obj_first_tri = ptr(self.obj_first_tri)
+        s.obj_num_tris = ptr(self.obj_num_tris)
+        s.num_objects = len(self.obj_first_tri)
+        s.mat_color = ptr(self.mat_color); s.mat_tex = ptr(self.mat_tex)
+        s.num_materials = len(self.mat_tex)
+        s.tex_data = ptr(self.tex_data); s.tex_offset = ptr(self.tex_offset)
+        s.tex_w = ptr(self.tex_w); s.tex_h = ptr(self.tex_h)
+        s.num_textures = self.num_textures
+        s.inst_pos = ptr(self.inst_pos); s.inst_rot = ptr(self.inst_rot)
+        s.inst_scale = ptr(self.inst_scale); s.inst_obj = ptr(self.inst_obj)
+        s.world_inst_start = ptr(self.world_inst_start)
+        s.cam_pos = ptr(self.cam_pos); s.cam_rot = ptr(self.cam_rot)
+        s.view_world = ptr(self.view_world)
+        s.num_views = self.num_views
+        s.width = self.width; s.height = self.height
+        sx, ox, sz, oz = projection_constants(self.width, self.height,
+                                              self.raytracer)
+        s.sx, s.ox, s.sz, s.oz = sx, ox, sz, oz
+        znear = _f32(RT_ZNEAR if self.raytracer else RASTER_ZNEAR)
+        s.inv_near = _f32(1.0) / znear
+        s.inv_far = (_f32(1.0) / _f32(RT_ZFAR)) if self.raytracer else _f32(0.0)
+        tl = to_light_vector()
+        s.to_light = (ctypes.c_float * 3)(*[float(x) for x in tl])
+        s.ambient = AMBIENT
+        s.diffuse = DIFFUSE
+        s.default_color = (ctypes.c_float * 4)(*DEFAULT_COLOR)
+        s.transposed = 1 if self.raytracer else 0
+        return s, keep
+
+    def render(self, view_begin=0, view_end=None, num_threads=0,
+               want_ids=True):
+        """-> dict(rgb [V,H,W,4] u8, depth [V,H,W] f32, tri_id, segmask)."""
+        if view_end is None:
+            view_end = self.num_views
+        V = self.num_views
+        # storage is [view][slow][fast]; raster (H, W); Raytracer (res, res)
+        nslow = self.width if self.raytracer else self.height
+        nfast = self.height if self.raytracer else self.width
+        rgb = np.zeros((V, nslow, nfast, 4), dtype=np.uint8)
+        depth = np.zeros((V, nslow, nfast), dtype=np.float32)
+        tri = np.full((V, nslow, nfast), -1, dtype=np.int32) if want_ids else None
+        seg = np.full((V, nslow, nfast), -1, dtype=np.int32) if want_ids else None
+        s, keep = self._struct()
+        used = lib().orc_render(ctypes.byref(s), int(view_begin), int(view_end),
+                                rgb.ctypes.data, depth.ctypes.data,
+                                tri.ctypes.data if want_ids else None,
+                                seg.ctypes.data if want_ids else None,
+                                int(num_threads))
+        del keep
+        return {"rgb": rgb, "depth": depth, "tri_id": tri, "segmask": seg,
+                "threads": used}
+
+
+def num_procs():
+    return lib().orc_num_procs()
