@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered views/sec of the batch-render hot path
+(Manager::step) on N MI355X, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one render of every view of the rank's worlds into the contiguous
+[views,H,W,4] RGBA8 + [views,H,W,1] f32 depth tensors; worlds shard across
+ranks with no data-path collective (weak scaling: --worlds per GPU).  Rank 0
+prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--wall", action="store_true", help="add wall_render.obj (config C3)")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time an RCCL all-gather of the output slabs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary 1024-world measurement")
+    ap.add_argument("--cpu-views", type=int, default=4096)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    return ap.parse_args()
+
+
+def timed_steps(r, steps, barrier):
+    """K back-to-back step() calls between barriers + device syncs.
+    Returns (wall seconds, device ms between HIP events on the launch stream)."""
+    import torch
+    barrier()
+    torch.cuda.synchronize()
+    r.sync()
+    t0 = time.perf_counter()
+    r.mark(0)
+    for _ in range(steps):
+        r.step()
+    r.mark(1)
+    r.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, r.elapsed_ms()
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this
+    same command (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(tag)
+    except Exception:
+        return None
+
+
+def main():
+    a = parse()
+    import torch
+    from madrona_renderer_amd import scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n_gpus = world if world > 1 else 1
+    if a.gpus != n_gpus and rank == 0:
+        print(f"note: --gpus {a.gpus} but WORLD_SIZE={world}; using {n_gpus}",
+              file=sys.stderr)
+    torch.cuda.set_device(local)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    desc = scenes.synthetic_scene(a.worlds, width=a.width, height=a.height,
+                                  with_wall=a.wall, first_world=rank * a.worlds)
+    r = scenes.make_renderer(desc, gpu_id=local)
+    views = desc.num_views
+    for _ in range(a.warmup):
+        r.step()
+    wall, dev_ms = timed_steps(r, a.steps, barrier)
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    total_views = views * n_gpus
+    value = total_views * a.steps / wall
+
+    bytes_per_launch = int(r.bytes_per_step())
+    kern_us = dev_ms * 1000.0 / a.steps
+    achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
+    out = {
+        "metric": "rendered views/sec (whole node), N worlds x 64x64 RGB+depth",
+        "value": value,
+        "unit": "views/s",
+        "n_gpus": n_gpus,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": wall * 1000.0 / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%d worlds/GPU x %dx%d RGBA8 + f32 depth, cube+plane%s, "
+                        "Rasterizer mode, one camera/world" % (
+                            a.worlds, a.width, a.height, "+wall" if a.wall else ""),
+            "worlds_per_gpu": a.worlds, "views_total": total_views,
+            "width": a.width, "height": a.height,
+            "parallelism": "worlds sharded x%d, no collective" % n_gpus,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": pmc_traffic("%dx%dx%d" % (a.worlds, a.width, a.height)),
+            "kernel": "mrx raster (one launch per step)",
+            "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch,
+        },
+    }
+
+    if a.gather and dist is not None:
+        rgb = r.rgb_tensor().to_torch()
+        dep = r.depth_tensor().to_torch()
+        g_rgb = torch.empty((n_gpus,) + tuple(rgb.shape), dtype=rgb.dtype, device="cuda")
+        g_dep = torch.empty((n_gpus,) + tuple(dep.shape), dtype=dep.dtype, device="cuda")
+        for _ in range(3):
+            dist.all_gather_into_tensor(g_rgb, rgb)
+            dist.all_gather_into_tensor(g_dep, dep)
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r.step()
+            dist.all_gather_into_tensor(g_rgb, rgb)
+            dist.all_gather_into_tensor(g_dep, dep)
+        torch.cuda.synchronize(); barrier()
+        gw = time.perf_counter() - t0
+        out["with_gather"] = {"value": total_views * a.steps / gw, "unit": "views/s",
+                              "ms_per_step": gw * 1000.0 / a.steps,
+                              "collective": "RCCL all_gather_into_tensor rgb+depth"}
+
+    if rank == 0 and n_gpus == 1 and not a.no_extra and a.worlds != 1024:
+        # BASELINE.json configs[1]: 1024 worlds, same scene, reported beside it
+        d2 = scenes.synthetic_scene(1024, width=a.width, height=a.height, with_wall=a.wall)
+        r2 = scenes.make_renderer(d2, gpu_id=local)
+        for _ in range(a.warmup):
+            r2.step()
+        w2, ms2 = timed_steps(r2, a.steps, lambda: None)
+        out["also"] = {"workload": "1024 worlds (BASELINE configs[1])",
+                       "value": 1024 * a.steps / w2, "unit": "views/s",
+                       "ms_per_step": w2 * 1000.0 / a.steps,
+                       "kernel_us": ms2 * 1000.0 / a.steps}
+        del r2
+
+    if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
+        # The reference has no CPU renderer (mgr.cpp:195-197); the baseline is
+        # this repo's scalar oracle on the host cores of this box.
+        from oracle import oracle
+        nv = min(a.cpu_views, views)
+        dcpu = scenes.synthetic_scene(nv, width=a.width, height=a.height, with_wall=a.wall)
+        fs = oracle.FlatScene(dcpu)
+        # a 1-GPU box owns a 16-core share of its host; stay inside it
+        nthr = max(1, min(len(os.sched_getaffinity(0)), a.cpu_threads))
+        fs.render(view_end=min(nv, 64), want_ids=False, num_threads=nthr)   # warm up
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = fs.render(want_ids=False, num_threads=nthr)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["cpu_baseline"] = {
+            "value": nv / best, "unit": "views/s", "cores": int(res["threads"]),
+            "kind": "port",
+            "sample": "%d views of the same scene, 1 step, best of 3, OpenMP over views"
+                      % nv,
+        }
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

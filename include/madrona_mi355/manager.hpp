@@ -90,6 +90,9 @@ public:
     // Additions with no counterpart in the reference (measurement / tests).
     madrona::py::Tensor visibilityTensor() const;   // needs MADRONA_MI355_VISIBILITY=1
     float timeRenders(int steps);                   // device ms for `steps` renders
+    void mark(int which);                           // HIP event 0/1 on the stream
+    float elapsedMs();                              // event1 - event0, waits for 1
+    uint64_t bytesPerStep() const;                  // algorithmic HBM bytes / render
     void *nativeHandle() const;                     // mrx_renderer *
 
     uint32_t numAgents;

@@ -173,6 +173,11 @@ void *mrx_stream(mrx_renderer *r);
  *    two HIP events on the renderer's stream; *ms_total = elapsed device ms.
  *    Synchronises the stream before returning. */
 int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total);
+/*    mrx_mark(r, 0 | 1) records HIP event 0 / 1 on the renderer's stream;
+ *    mrx_elapsed_ms waits for event 1 and returns event1 - event0.  They let a
+ *    caller bracket its own timed region of mrx_step calls with device time. */
+int mrx_mark(mrx_renderer *r, int which);
+int mrx_elapsed_ms(mrx_renderer *r, float *ms);
 
 /* -- loader cross-check (host copies of what was uploaded) */
 int mrx_copy_triangles(mrx_renderer *r, float *tri_pos /*[T][9]*/,

@@ -161,6 +161,28 @@ float Manager::timeRenders(int steps)
     return ms;
 }
 
+void Manager::mark(int which)
+{
+    if (mrx_mark(impl_->r, which) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
+float Manager::elapsedMs()
+{
+    float ms = 0.f;
+    if (mrx_elapsed_ms(impl_->r, &ms) != MRX_OK)
+        detail::fatal(mrx_last_error());
+    return ms;
+}
+
+uint64_t Manager::bytesPerStep() const
+{
+    mrx_info_t info {};
+    if (mrx_info(impl_->r, &info) != MRX_OK)
+        detail::fatal(mrx_last_error());
+    return info.bytes_per_step;
+}
+
 void *Manager::nativeHandle() const { return impl_->r; }
 
 }  // namespace madRender

@@ -509,6 +509,25 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
     return MRX_OK;
 }
 
+int mrx_mark(mrx_renderer *r, int which)
+{
+    if (!r || (which != 0 && which != 1))
+        return fail(MRX_E_INVALID, "bad argument");
+    MRX_HIP(hipSetDevice(r->device));
+    MRX_HIP(hipEventRecord(which ? r->ev1 : r->ev0, r->stream));
+    return MRX_OK;
+}
+
+int mrx_elapsed_ms(mrx_renderer *r, float *ms)
+{
+    if (!r || !ms)
+        return fail(MRX_E_INVALID, "null argument");
+    MRX_HIP(hipSetDevice(r->device));
+    MRX_HIP(hipEventSynchronize(r->ev1));
+    MRX_HIP(hipEventElapsedTime(ms, r->ev0, r->ev1));
+    return MRX_OK;
+}
+
 int mrx_copy_triangles(mrx_renderer *r, float *tri_pos, float *tri_uv, int32_t *tri_mat,
                        int32_t *obj_first, int32_t *obj_count)
 {

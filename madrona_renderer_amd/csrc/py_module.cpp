@@ -307,6 +307,9 @@ PYBIND11_MODULE(madrona_renderer, m)
                  return wrapTensor(self, self.cast<Manager &>().cameraRotationTensor());
              })
         .def("time_renders", &Manager::timeRenders, py::arg("steps"))
+        .def("mark", &Manager::mark, py::arg("which"))
+        .def("elapsed_ms", &Manager::elapsedMs)
+        .def("bytes_per_step", &Manager::bytesPerStep)
         .def("native_handle", [](Manager &self) { return (uint64_t)self.nativeHandle(); })
         .def_readonly("num_agents", &Manager::numAgents);
 }

@@ -126,7 +126,8 @@ def _f32t(*xs):
 
 
 def synthetic_scene(num_worlds, width=64, height=64, with_wall=False,
-                    textured=False, render_mode="Rasterizer", data_dir=None):
+                    textured=False, render_mode="Rasterizer", data_dir=None,
+                    first_world=0):
     """Cube + ground plane (+ wall) per world, one camera per world on a ring
     looking at the origin."""
     dd = DATA_DIR if data_dir is None else data_dir
@@ -138,7 +139,9 @@ def synthetic_scene(num_worlds, width=64, height=64, with_wall=False,
     materials = [((0.588, 0.588, 0.588, 1.0), -1, 0.8, 0.2),
                  ((1.0, 1.0, 1.0, 1.0), 0, 0.8, 0.2)]
     n_inst = 3 if with_wall else 2
-    w = np.arange(num_worlds, dtype=np.uint64)
+    # world ids are global: rank r of a sharded job passes first_world = its
+    # offset and gets exactly the rows it would own of the whole job's scene
+    w = np.arange(first_world, first_world + num_worlds, dtype=np.uint64)
     u = [uniform(w * np.uint64(16) + np.uint64(j)) for j in range(12)]
     instances, cameras, worlds = [], [], []
     for i in range(num_worlds):

@@ -1,0 +1,220 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports what
+include/mrx.h declares, the asset readers agree with independent decoders, the
+API fails loudly without a GPU, and the scene helpers are deterministic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from madrona_renderer_amd import scenes
+from tests.conftest import ROOT, has_gpu
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mrx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_capi_exports_every_declared_symbol(native):
+    lib = native.load_capi()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"libmrx_hip.so does not export {n}"
+    lib.mrx_abi_version.restype = ctypes.c_int
+    assert lib.mrx_abi_version() == 1
+
+
+def test_module_surface_matches_reference_bindings(native):
+    # /root/reference/src/bindings.cpp:21-233
+    m = native.load_module()
+    for cls in ("RenderMode", "ImportedAsset", "AdditionalMaterial", "ImportedInstance",
+                "ImportedCamera", "WorldInit", "MadronaRenderer", "inspect"):
+        assert hasattr(m, cls), cls
+    assert {"Rasterizer", "Raytracer"} <= set(m.RenderMode.__members__)
+    for meth in ("step", "rgb_tensor", "depth_tensor", "segmask_tensor", "rgb_cuda_ptr",
+                 "depth_cuda_ptr", "segmask_cuda_ptr", "instance_position_tensor",
+                 "instance_rotation_tensor", "camera_position_tensor",
+                 "camera_rotation_tensor"):
+        assert hasattr(m.MadronaRenderer, meth), meth
+    m.ImportedInstance(position=[0, 0, 0], rotation=[1, 0, 0, 0], scale=[1, 1, 1], object_id=0)
+    m.WorldInit(num_instances=1, instance_offset=0, num_cameras=1, camera_offset=0)
+    with pytest.raises(TypeError):
+        m.ImportedInstance(position=[0, 0], rotation=[1, 0, 0, 0], scale=[1, 1, 1], object_id=0)
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_a_gpu(native):
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        scenes.make_renderer(scenes.demo_scene())
+    lib = native.load_capi()
+    assert lib.mrx_device_count() == 0
+
+
+def _load_obj(lib, path):
+    pp = ctypes.POINTER(ctypes.c_float)()
+    uu = ctypes.POINTER(ctypes.c_float)()
+    n = ctypes.c_uint32()
+    rc = lib.mrx_load_obj(path.encode(), ctypes.byref(pp), ctypes.byref(uu), ctypes.byref(n))
+    if rc != 0:
+        return rc, None, None
+    pos = np.ctypeslib.as_array(pp, shape=(n.value, 3, 3)).copy() if n.value else np.zeros((0, 3, 3))
+    uv = np.ctypeslib.as_array(uu, shape=(n.value, 3, 2)).copy() if n.value else np.zeros((0, 3, 2))
+    lib.mrx_free(pp)
+    lib.mrx_free(uu)
+    return 0, pos, uv
+
+
+def _decode_png(lib, path):
+    img = ctypes.POINTER(ctypes.c_uint8)()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = lib.mrx_decode_png(path.encode(), ctypes.byref(img), ctypes.byref(w), ctypes.byref(h))
+    if rc != 0:
+        return rc, None
+    a = np.ctypeslib.as_array(img, shape=(h.value, w.value, 4)).copy()
+    lib.mrx_free(img)
+    return 0, a
+
+
+@pytest.mark.parametrize("name,ntris", [("cube.obj", 12), ("plane.obj", 2),
+                                        ("wall_render.obj", 12)])
+def test_obj_reader_matches_independent_parser(native, oracle_mod, name, ntris):
+    lib = native.load_capi()
+    path = os.path.join(scenes.DATA_DIR, name)
+    rc, pos, uv = _load_obj(lib, path)
+    assert rc == 0 and pos.shape == (ntris, 3, 3)
+    rp, ru = oracle_mod.parse_obj(path)
+    assert np.array_equal(pos, rp) and np.array_equal(uv, ru)
+
+
+def test_obj_reader_polygons_negative_indices_missing_uv(native, oracle_mod, tmp_path):
+    p = tmp_path / "quad.obj"
+    p.write_text("# quad + pentagon, relative indices, no vt on the second face\n"
+                 "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 1.5 0.25\n"
+                 "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                 "f 1/1 2/2 3/3 4/4\n"
+                 "f -5//1 -4//1 -3//1 -1//1 -2//1\n")
+    lib = native.load_capi()
+    rc, pos, uv = _load_obj(lib, str(p))
+    assert rc == 0 and pos.shape == (2 + 3, 3, 3)
+    rp, ru = oracle_mod.parse_obj(str(p))
+    assert np.array_equal(pos, rp) and np.array_equal(uv, ru)
+    assert np.all(uv[2:] == 0)
+
+
+def test_obj_reader_errors(native, tmp_path):
+    lib = native.load_capi()
+    lib.mrx_last_error.restype = ctypes.c_char_p
+    rc, _, _ = _load_obj(lib, str(tmp_path / "missing.obj"))
+    assert rc == -4 and b"cannot open" in lib.mrx_last_error()
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    rc, _, _ = _load_obj(lib, str(bad))
+    assert rc == -4 and b"out of range" in lib.mrx_last_error()
+    empty = tmp_path / "empty.obj"
+    empty.write_text("")
+    rc, pos, _ = _load_obj(lib, str(empty))
+    assert rc == 0 and pos.shape[0] == 0
+
+
+def test_png_decoder_reference_texture(native, oracle_mod):
+    # data/cube.png: 256x256, 8-bit palette, one IDAT
+    lib = native.load_capi()
+    path = os.path.join(scenes.DATA_DIR, "cube.png")
+    rc, a = _decode_png(lib, path)
+    assert rc == 0 and a.shape == (256, 256, 4)
+    assert np.array_equal(a, oracle_mod.decode_image(path))
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P", "P-trns", "1", "I;16"])
+def test_png_decoder_variants_match_pillow(native, oracle_mod, tmp_path, mode):
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    w, h = 37, 23                      # odd sizes exercise the filters' edges
+    if mode in ("RGB", "RGBA", "L", "LA"):
+        ch = {"RGB": 3, "RGBA": 4, "L": 1, "LA": 2}[mode]
+        # smooth + noise so every PNG filter type gets picked
+        base = (np.add.outer(np.arange(h), np.arange(w)) * 3)[..., None]
+        arr = ((base + rng.integers(0, 40, (h, w, ch))) % 256).astype(np.uint8)
+        im = Image.fromarray(arr.squeeze() if ch == 1 else arr, mode)
+    elif mode.startswith("P"):
+        arr = rng.integers(0, 200, (h, w)).astype(np.uint8)
+        im = Image.fromarray(arr, "P")
+        im.putpalette(rng.integers(0, 256, 768).astype(np.uint8).tolist())
+        if mode == "P-trns":
+            im.info["transparency"] = bytes(rng.integers(0, 256, 200).astype(np.uint8))
+    elif mode == "1":
+        im = Image.fromarray(rng.integers(0, 2, (h, w)).astype(bool))
+    else:
+        im = Image.fromarray(rng.integers(0, 65536, (h, w)).astype(np.uint16))
+    path = str(tmp_path / f"t_{mode.replace(';', '')}.png")
+    kw = {"transparency": im.info["transparency"]} if mode == "P-trns" else {}
+    im.save(path, **kw)
+    lib = native.load_capi()
+    rc, a = _decode_png(lib, path)
+    assert rc == 0
+    if mode == "I;16":
+        # 16-bit samples are reduced to their high byte
+        with Image.open(path) as r:
+            hi = (np.asarray(r).astype(np.uint16) >> 8).astype(np.uint8)
+        assert np.array_equal(a[..., 0], hi) and np.all(a[..., 3] == 255)
+    else:
+        assert np.array_equal(a, oracle_mod.decode_image(path))
+
+
+def test_png_decoder_errors(native, tmp_path):
+    lib = native.load_capi()
+    lib.mrx_last_error.restype = ctypes.c_char_p
+    p = tmp_path / "x.png"
+    p.write_bytes(b"not a png at all")
+    rc, _ = _decode_png(lib, str(p))
+    assert rc == -4 and b"not a PNG" in lib.mrx_last_error()
+    good = open(os.path.join(scenes.DATA_DIR, "cube.png"), "rb").read()
+    p.write_bytes(good[:2000])
+    rc, _ = _decode_png(lib, str(p))
+    assert rc == -4
+
+
+def test_pod_layouts_match_the_reference_structs():
+    # sizes fixed by /root/reference/src/sim.hpp:31-50,76-82 and bindings.cpp:44-49
+    text = open(os.path.join(ROOT, "include", "madrona_mi355", "types.hpp")).read()
+    for s, n in (("ImportedInstance", 44), ("ImportedCamera", 28),
+                 ("Sim::WorldInit", 16), ("madrona::imp::SourceMaterial", 28)):
+        assert f"sizeof({s}) == {n}" in text
+
+
+def test_rng_and_scene_are_deterministic():
+    # splitmix64 known answers (seed 0x4D52584D xor k), exact in float32
+    u = scenes.uniform(np.arange(4))
+    assert np.all((u >= 0) & (u < 1))
+    assert np.array_equal(u.astype(np.float32).astype(np.float64), u)
+    a = scenes.synthetic_scene(8, with_wall=True)
+    b = scenes.synthetic_scene(8, with_wall=True)
+    assert a.instances == b.instances and a.cameras == b.cameras
+    # a shard generated on its own equals the slice of the whole job's scene
+    whole = scenes.synthetic_scene(8)
+    part = scenes.synthetic_scene(4, first_world=4)
+    assert part.instances == whole.instances[8:] and part.cameras == whole.cameras[4:]
+    # every camera looks at (0,0,1): its +Y axis points from eye to target
+    for (eye, q) in whole.cameras:
+        w, x, y, z = q
+        fwd = np.array([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)])
+        to = np.array([0, 0, 1.0]) - np.array(eye)
+        assert np.dot(fwd, to / np.linalg.norm(to)) > 0.9999
+
+
+def test_shard_ranges_partition_the_worlds():
+    for n in (0, 1, 7, 8, 4096, 16384, 16385):
+        for ws in (1, 2, 3, 8):
+            spans = [scenes.shard_range(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    d = scenes.synthetic_scene(10)
+    s = d.shard(1, 4)
+    assert s.num_worlds == 3 and s.worlds == d.worlds[3:6]

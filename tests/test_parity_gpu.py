@@ -1,0 +1,294 @@
+"""Parity of the HIP path against the CPU oracle on the same seeded inputs
+(-m gpu; calls go through the compiled module -> Manager -> C-ABI -> kernels).
+
+Bar (BASELINE.json north_star): coverage / visibility bit-exact, colour and
+depth within 1e-4.  Colour is in fact compared for equality of the RGBA8 bytes
+and depth to rtol 1e-4 (it is bit-exact today; the tolerance is the contract).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from madrona_renderer_amd import scenes
+from tests.util import assert_parity, fetch, make_product, render_oracle
+
+pytestmark = pytest.mark.gpu
+
+CUBE = os.path.join(scenes.DATA_DIR, "cube.obj")
+PLANE = os.path.join(scenes.DATA_DIR, "plane.obj")
+IDENT = (1.0, 0.0, 0.0, 0.0)
+
+
+def _parity(desc, **kw):
+    r = make_product(desc, visibility=True)
+    got = fetch(r)
+    ref = render_oracle(desc)
+    assert_parity(got, ref, **kw)
+    return r, got, ref
+
+
+@pytest.mark.parametrize("mode", ["Rasterizer", "Raytracer"])
+def test_reference_demo_scene(native, mode):
+    # /root/reference/scripts/test.py: 4 worlds aliasing rows, cube + raw triangle
+    _, got, _ = _parity(scenes.demo_scene(num_worlds=4, render_mode=mode))
+    assert got["rgb"].shape == (4, 64, 64, 4)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(num_worlds=64),
+    dict(num_worlds=64, with_wall=True, textured=True),
+    dict(num_worlds=16, width=128, height=128, with_wall=True),
+    dict(num_worlds=8, width=96, height=40),            # ragged tiles
+    dict(num_worlds=8, width=32, height=32),            # smaller than a tile
+    dict(num_worlds=4, width=200, height=72, textured=True),
+    dict(num_worlds=8, width=256, height=256, textured=True, render_mode="Raytracer"),
+    dict(num_worlds=5, width=80, height=80, with_wall=True, render_mode="Raytracer"),
+], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_synthetic_scenes(native, kw):
+    _parity(scenes.synthetic_scene(**kw))
+
+
+def test_headline_config_full_size(native):
+    # BASELINE north star: 4096 worlds x 64x64 -- every pixel of every view
+    desc = scenes.synthetic_scene(4096)
+    r = make_product(desc, visibility=True)
+    got = fetch(r)
+    ref = render_oracle(desc)
+    assert_parity(got, ref)
+    assert (ref["tri_id"] >= 0).mean() > 0.6
+    # without the visibility buffer (the benchmarked configuration) the
+    # RGB / depth bytes are the same
+    r2 = make_product(desc, visibility=False)
+    got2 = fetch(r2, visibility=False)
+    assert np.array_equal(got2["rgb"], got["rgb"])
+    assert np.array_equal(got2["depth"], got["depth"])
+
+
+def test_config_c3_4096_worlds_128(native):
+    desc = scenes.synthetic_scene(4096, width=128, height=128, with_wall=True)
+    r = make_product(desc, visibility=False)
+    got = fetch(r, visibility=False)
+    ref = render_oracle(desc, want_ids=False)
+    assert_parity(got, ref)
+
+
+def test_pose_tensors_are_live_and_stepping_rerenders(native):
+    # scripts/test.py:137-151: mutate instance_position_tensor in place, step
+    import torch
+    desc = scenes.demo_scene(num_worlds=4, render_mode="Rasterizer")
+    r = make_product(desc)
+    pos = r.instance_position_tensor().to_torch()
+    rot = r.instance_rotation_tensor().to_torch()
+    cpos = r.camera_position_tensor().to_torch()
+    crot = r.camera_rotation_tensor().to_torch()
+    assert pos.is_cuda and tuple(pos.shape) == (8, 3) and tuple(rot.shape) == (8, 4)
+    assert tuple(cpos.shape) == (4, 3) and tuple(crot.shape) == (4, 4)
+    before = fetch(r)
+    for s in range(3):
+        pos[0][2] += 1.0
+        pos[2][2] += 2.0
+        pos[4][2] += 1.5
+        pos[6][2] += 0.5
+        cpos[1][0] -= 0.75
+        torch.cuda.synchronize()
+        r.step()
+    got = fetch(r)
+    assert not np.array_equal(got["rgb"], before["rgb"])
+    # oracle on the same mutated per-world rows (worlds own copies of the rows)
+    d2 = scenes.demo_scene(num_worlds=4, render_mode="Rasterizer")
+    inst = []
+    for w, dz in enumerate((1.0, 2.0, 1.5, 0.5)):
+        (p, q, s_, o), tri = d2.instances[0], d2.instances[1]
+        z = np.float32(p[2])
+        for _ in range(3):
+            z = np.float32(z + np.float32(dz))
+        inst += [((p[0], p[1], float(z)), q, s_, o), tri]
+    d2.instances = inst
+    cams = [d2.cameras[0]] * 4
+    x = np.float32(cams[1][0][0])
+    for _ in range(3):
+        x = np.float32(x - np.float32(0.75))
+    cams[1] = ((float(x),) + tuple(cams[1][0][1:]), cams[1][1])
+    d2.cameras = cams
+    d2.worlds = [(2, 2 * w, 1, w) for w in range(4)]
+    assert_parity(got, render_oracle(d2))
+
+
+def test_rendering_is_deterministic(native):
+    desc = scenes.synthetic_scene(256, with_wall=True, textured=True)
+    r = make_product(desc)
+    a = fetch(r)
+    r.step()
+    r.render()
+    b = fetch(r)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+
+
+def _world(instances, assets, cams, **kw):
+    return scenes.SceneDesc(num_worlds=1, asset_paths=assets, instances=instances,
+                            cameras=cams, worlds=[(len(instances), 0, len(cams), 0)], **kw)
+
+
+def test_more_than_64_triangles_per_world_uses_chunks(native):
+    # 9 cubes + plane = 110 triangles: two setup chunks per band
+    rng = np.random.default_rng(3)
+    inst = [((0.0, 0.0, 0.0), IDENT, (1.0, 1.0, 1.0), 1)]
+    for _ in range(9):
+        p = rng.uniform(-5, 5, 3)
+        inst.append(((float(p[0]), float(p[1]), float(abs(p[2]))), IDENT,
+                     (1.5, 1.0, 2.0), 0))
+    cams = [((12.0, -9.0, 7.0), scenes.look_at((12.0, -9.0, 7.0), (0, 0, 1))),
+            ((-3.0, 14.0, 3.0), scenes.look_at((-3.0, 14.0, 3.0), (0, 0, 1)))]
+    d = _world(inst, [(CUBE, 0), (PLANE, 1)], cams,
+               materials=[((0.9, 0.4, 0.2, 1.0), 0, 0.5, 0.5), ((0.3, 0.6, 0.3, 1.0), -1, 0.5, 0.5)],
+               texture_paths=[os.path.join(scenes.DATA_DIR, "cube.png")], width=128, height=64)
+    _, got, _ = _parity(d)
+    assert got["rgb"].shape == (2, 64, 128, 4)
+    assert got["tri_id"].max() >= 64
+
+
+def test_edge_cases_empty_worlds_bad_ids_degenerate_triangles(native):
+    verts = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0],        # collinear: zero area
+                      [0, 0, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+    d = scenes.SceneDesc(
+        num_worlds=4, width=64, height=64,
+        asset_paths=[(CUBE, -1)],
+        mesh_vertices=verts, mesh_uvs=np.zeros((6, 2), np.float32),
+        mesh_indices=np.array([0, 1, 2, 0, 1, 2], np.uint32),
+        mesh_vertex_offsets=np.array([0, 3], np.uint32),
+        mesh_indices_offsets=np.array([0, 3], np.uint32),
+        mesh_materials=np.array([-1, 7], np.int32),            # 7: no such material
+        instances=[((0.0, 5.0, 0.0), IDENT, (1.0, 1.0, 1.0), 0),
+                   ((0.0, 4.0, 0.0), IDENT, (1.0, 1.0, 1.0), 1),   # degenerate
+                   ((0.0, 3.0, -0.5), IDENT, (1.0, 1.0, 1.0), 2),
+                   ((0.0, 2.0, 0.0), IDENT, (1.0, 1.0, 1.0), 9),   # no such object
+                   ((0.0, 2.0, 0.0), IDENT, (1.0, 1.0, 1.0), -1),
+                   ((0.0, 6.0, 0.0), IDENT, (0.0, 0.0, 0.0), 0)],  # zero scale
+        cameras=[((0.0, 0.0, 0.0), IDENT), ((0.0, 10.0, 0.0), (0.0, 0.0, 0.0, 1.0))],
+        worlds=[(6, 0, 1, 0),      # everything
+                (0, 0, 1, 1),      # empty world: background only
+                (2, 3, 2, 0),      # only invalid ids, two cameras
+                (1, 1, 0, 0)])     # no camera at all
+    r, got, ref = _parity(d)
+    assert got["rgb"].shape[0] == 4            # 1 + 1 + 2 + 0 views
+    assert (got["tri_id"][1] == -1).all() and (got["depth"][1] == 0).all()
+    assert (got["tri_id"][2] == -1).all() and (got["tri_id"][3] == -1).all()
+    assert (got["tri_id"][0] >= 0).any()
+
+
+def test_error_behaviour(native):
+    m = native.load_module()
+    r = make_product(scenes.demo_scene(num_worlds=1, render_mode="Rasterizer"), visibility=False)
+    # /root/reference/src/mgr.cpp:594-596: FATAL("Segmask not implemented for rasterizer")
+    with pytest.raises(RuntimeError, match="Segmask not implemented for rasterizer"):
+        r.segmask_tensor()
+    with pytest.raises(RuntimeError):
+        r.visibility_tensor()
+    bad = scenes.demo_scene(num_worlds=1)
+    bad.asset_paths = [("/nonexistent/file.obj", 0)]
+    with pytest.raises(RuntimeError, match="Failed to load render assets"):
+        scenes.make_renderer(bad)
+    bad = scenes.demo_scene(num_worlds=1)
+    bad.worlds = [(5, 0, 1, 0)]
+    with pytest.raises(RuntimeError, match="outside the tables"):
+        scenes.make_renderer(bad)
+    with pytest.raises(RuntimeError, match="gpu_id"):
+        scenes.make_renderer(scenes.demo_scene(num_worlds=1), gpu_id=99)
+    rt = make_product(scenes.demo_scene(num_worlds=1, render_mode="Raytracer"), visibility=False)
+    seg = rt.segmask_tensor().to_torch()
+    assert tuple(seg.shape) == (1, 64, 64) and str(seg.dtype) == "torch.int32"
+    assert rt.rgb_cuda_ptr() == rt.rgb_tensor().device_ptr() != 0
+    assert tuple(rt.depth_tensor().to_torch().shape) == (1, 64, 64)
+
+
+def test_raw_c_abi_through_ctypes(native):
+    """The boundary itself, without the C++/pybind layers."""
+    lib = native.load_capi()
+
+    class Geo(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in
+                    ("vertices", "uvs", "indices", "mvo", "mio", "mm")] + \
+                   [(n, ctypes.c_uint32) for n in ("nv", "ni", "nm")]
+
+    class Cfg(ctypes.Structure):
+        _fields_ = [("struct_size", ctypes.c_uint32), ("gpu_id", ctypes.c_int32),
+                    ("num_worlds", ctypes.c_uint32), ("render_mode", ctypes.c_int32),
+                    ("view_width", ctypes.c_uint32), ("view_height", ctypes.c_uint32),
+                    ("geo", Geo),
+                    ("asset_paths", ctypes.POINTER(ctypes.c_char_p)), ("num_asset_paths", ctypes.c_uint32),
+                    ("mat_assignments", ctypes.POINTER(ctypes.c_int32)), ("num_mat_assignments", ctypes.c_uint32),
+                    ("materials", ctypes.c_void_p), ("num_materials", ctypes.c_uint32),
+                    ("texture_paths", ctypes.POINTER(ctypes.c_char_p)), ("num_textures", ctypes.c_uint32),
+                    ("instances", ctypes.c_void_p), ("num_instances", ctypes.c_uint32),
+                    ("cameras", ctypes.c_void_p), ("num_cameras", ctypes.c_uint32),
+                    ("worlds", ctypes.c_void_p),
+                    ("stream", ctypes.c_void_p), ("flags", ctypes.c_uint32),
+                    ("kernel_variant", ctypes.c_int32)]
+
+    desc = scenes.synthetic_scene(3)
+    inst = np.zeros((len(desc.instances), 11), np.float32)
+    for i, (p, q, s, o) in enumerate(desc.instances):
+        inst[i, :3], inst[i, 3:7], inst[i, 7:10] = p, q, s
+        inst[i, 10:11].view(np.int32)[0] = o
+    cams = np.array([list(p) + list(q) for p, q in desc.cameras], np.float32)
+    worlds = np.array(desc.worlds, np.uint32)
+    mats = np.zeros((len(desc.materials), 7), np.float32)
+    for i, (c, t, ro, me) in enumerate(desc.materials):
+        mats[i, :4] = c
+        mats[i, 4:5].view(np.int32)[0] = t
+        mats[i, 5], mats[i, 6] = ro, me
+    paths = (ctypes.c_char_p * 2)(*[p.encode() for p, _ in desc.asset_paths])
+    assign = (ctypes.c_int32 * 2)(*[i for _, i in desc.asset_paths])
+    tex = (ctypes.c_char_p * 1)(desc.texture_paths[0].encode())
+    cfg = Cfg()
+    cfg.struct_size = ctypes.sizeof(Cfg)
+    cfg.gpu_id, cfg.num_worlds, cfg.render_mode = 0, 3, 0
+    cfg.view_width = cfg.view_height = 64
+    cfg.asset_paths, cfg.num_asset_paths = paths, 2
+    cfg.mat_assignments, cfg.num_mat_assignments = assign, 2
+    cfg.materials, cfg.num_materials = mats.ctypes.data, len(mats)
+    cfg.texture_paths, cfg.num_textures = tex, 1
+    cfg.instances, cfg.num_instances = inst.ctypes.data, len(inst)
+    cfg.cameras, cfg.num_cameras = cams.ctypes.data, len(cams)
+    cfg.worlds = worlds.ctypes.data
+    cfg.flags = 1
+    h = ctypes.c_void_p()
+    lib.mrx_last_error.restype = ctypes.c_char_p
+    lib.mrx_buffer.restype = ctypes.c_void_p
+    assert lib.mrx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0, lib.mrx_last_error()
+    bad = Cfg.from_buffer_copy(cfg)
+    bad.struct_size = 8
+    h2 = ctypes.c_void_p()
+    assert lib.mrx_create(ctypes.byref(bad), ctypes.byref(h2)) == -1
+    assert b"size mismatch" in lib.mrx_last_error()
+    assert lib.mrx_step(h) == 0 and lib.mrx_render(h) == 0 and lib.mrx_sync(h) == 0
+    dims = (ctypes.c_int64 * 4)()
+    nd, dt, dev = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    p = lib.mrx_buffer(h, 0, dims, ctypes.byref(nd), ctypes.byref(dt), ctypes.byref(dev))
+    assert p and list(dims) == [3, 64, 64, 4] and nd.value == 4 and dt.value == 0
+    assert lib.mrx_buffer(h, 2, dims, ctypes.byref(nd), ctypes.byref(dt), ctypes.byref(dev)) is None
+    assert lib.mrx_buffer(h, 99, dims, ctypes.byref(nd), ctypes.byref(dt), ctypes.byref(dev)) is None
+    import torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    host = np.empty((3, 64, 64, 4), np.uint8)
+    assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(p),
+                         ctypes.c_size_t(host.nbytes), 2) == 0
+    ref = render_oracle(desc)
+    assert np.array_equal(host, ref["rgb"])
+    # loader cross-check: what was uploaded equals the independent parse
+    from oracle import oracle
+    fs = oracle.FlatScene(desc)
+    n = len(fs.tri_mat)
+    tp = np.empty((n, 9), np.float32); tu = np.empty((n, 6), np.float32)
+    tm = np.empty(n, np.int32); of = np.empty(2, np.int32); oc = np.empty(2, np.int32)
+    assert lib.mrx_copy_triangles(h, tp.ctypes.data_as(ctypes.c_void_p), tu.ctypes.data_as(ctypes.c_void_p),
+                                  tm.ctypes.data_as(ctypes.c_void_p), of.ctypes.data_as(ctypes.c_void_p),
+                                  oc.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(tp.reshape(-1, 3, 3), fs.tri_pos) and np.array_equal(tu.reshape(-1, 3, 2), fs.tri_uv)
+    assert np.array_equal(tm, fs.tri_mat) and np.array_equal(of, fs.obj_first_tri)
+    ms = ctypes.c_float()
+    assert lib.mrx_time_renders(h, 5, ctypes.byref(ms)) == 0 and ms.value > 0
+    lib.mrx_destroy(h)
