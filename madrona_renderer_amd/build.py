@@ -67,6 +67,14 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     if force or _stale(out, HIP_DEPS):
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
                "-shared", "-ffp-contract=off", "-fno-fast-math",
+               # per-pixel state lives in small unrolled arrays; LLVM's AMDGPU
+               # promote-alloca pass turns them into 16-wide vector registers
+               # whose every conditional update copies the whole tuple
+               "-mllvm", "-disable-promote-alloca-to-vector",
+               # the SLP vectorizer packs scalar f32 math into v_pk_* pairs and
+               # pays for it in v_mov shuffles and ~40 extra VGPRs (no rate gain
+               # on gfx950: packed f32 issues at the scalar-f32 rate)
+               "-fno-slp-vectorize",
                "-Wall", "-Wno-unused-function"]
         cmd += list(extra_flags)
         cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]

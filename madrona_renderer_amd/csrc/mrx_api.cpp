@@ -81,11 +81,11 @@ struct mrx_renderer {
     std::vector<int32_t> objFirst, objCount;
     // device state
     DevBuf<mrx::ObjTri> tris;
-    DevBuf<mrx::Material> materials;
+    DevBuf<mrx::TriMat> triMats;
     DevBuf<mrx::TexDesc> textures;
     DevBuf<uint32_t> texels;
-    DevBuf<mrx::WorldTri> worldTris;
-    DevBuf<uint32_t> worldTriStart, viewWorld;
+    DevBuf<mrx::WorldTri> viewTris;
+    DevBuf<uint32_t> viewTriCount;
     DevBuf<float> instPos, instRot, instScale, camPos, camRot;
     DevBuf<int32_t> instObj;
     DevBuf<uint32_t> rgb;
@@ -96,8 +96,8 @@ struct mrx_renderer {
     ~mrx_renderer()
     {
         (void)hipSetDevice(device);
-        tris.release(); materials.release(); textures.release(); texels.release();
-        worldTris.release(); worldTriStart.release(); viewWorld.release();
+        tris.release(); triMats.release(); textures.release(); texels.release();
+        viewTris.release(); viewTriCount.release();
         instPos.release(); instRot.release(); instScale.release();
         camPos.release(); camRot.release(); instObj.release();
         rgb.release(); depth.release(); ids.release();
@@ -178,10 +178,21 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         texels.resize(texels.size() + n);
         std::memcpy(texels.data() + d.offset, img.rgba.data(), n * 4);
     }
-    std::vector<Material> mats(cfg.num_materials);
-    for (uint32_t m = 0; m < cfg.num_materials; ++m) {
-        std::memcpy(mats[m].color, cfg.materials[m].color, 16);
-        mats[m].tex = cfg.materials[m].texture_idx;
+    // resolve every object triangle's material once: mesh material if it
+    // exists, else the default colour (white, untextured); a texture index
+    // with no texture behind it means untextured
+    std::vector<TriMat> triMats(tris.size());
+    for (size_t t = 0; t < tris.size(); ++t) {
+        TriMat &tm = triMats[t];
+        tm.color[0] = tm.color[1] = tm.color[2] = tm.color[3] = 1.0f;
+        tm.tex = -1;
+        const int32_t m = tris[t].mat;
+        if (m >= 0 && (uint32_t)m < cfg.num_materials) {
+            std::memcpy(tm.color, cfg.materials[m].color, 16);
+            tm.tex = cfg.materials[m].texture_idx;
+        }
+        if (tm.tex < 0 || (uint32_t)tm.tex >= (uint32_t)texDescs.size())
+            tm.tex = -1;
     }
 
     // ---- world assembly: per-world copies of the table rows, world-major
@@ -189,7 +200,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     std::vector<float> instPos, instRot, instScale, camPos, camRot;
     std::vector<int32_t> instObj;
     std::vector<uint32_t> worldTriStart(1, 0), viewWorld;
-    std::vector<WorldTri> worldTris;
+    std::vector<WorldTri> worldTris;   // per world; expanded per view below
     uint32_t maxWorldTris = 0;
     for (uint32_t w = 0; w < cfg.num_worlds; ++w) {
         const mrx_world_init &wi = cfg.worlds[w];
@@ -224,12 +235,21 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
 
     // ---- upload
     MRX_HIP(r.tris.upload(tris));
-    MRX_HIP(r.materials.upload(mats));
+    MRX_HIP(r.triMats.upload(triMats));
     MRX_HIP(r.textures.upload(texDescs));
     MRX_HIP(r.texels.upload(texels));
-    MRX_HIP(r.worldTris.upload(worldTris));
-    MRX_HIP(r.worldTriStart.upload(worldTriStart));
-    MRX_HIP(r.viewWorld.upload(viewWorld));
+    // per-view draw lists with a fixed stride (one load level in the kernel)
+    const uint32_t stride = maxWorldTris ? maxWorldTris : 1u;
+    std::vector<WorldTri> viewTris((size_t)viewWorld.size() * stride, WorldTri { 0, 0 });
+    std::vector<uint32_t> viewTriCount(viewWorld.size());
+    for (size_t v = 0; v < viewWorld.size(); ++v) {
+        const uint32_t w = viewWorld[v];
+        const uint32_t b = worldTriStart[w], n = worldTriStart[w + 1] - b;
+        viewTriCount[v] = n;
+        std::memcpy(viewTris.data() + v * stride, worldTris.data() + b, n * sizeof(WorldTri));
+    }
+    MRX_HIP(r.viewTris.upload(viewTris));
+    MRX_HIP(r.viewTriCount.upload(viewTriCount));
     MRX_HIP(r.instPos.upload(instPos));
     MRX_HIP(r.instRot.upload(instRot));
     MRX_HIP(r.instScale.upload(instScale));
@@ -254,14 +274,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
 
     RasterParams &p = r.params;
     p.tris = r.tris.ptr;
-    p.materials = r.materials.ptr;
+    p.triMats = r.triMats.ptr;
     p.textures = r.textures.ptr;
     p.texels = r.texels.ptr;
-    p.numMaterials = (uint32_t)mats.size();
-    p.numTextures = (uint32_t)texDescs.size();
-    p.worldTris = r.worldTris.ptr;
-    p.worldTriStart = r.worldTriStart.ptr;
-    p.viewWorld = r.viewWorld.ptr;
+    p.viewTris = r.viewTris.ptr;
+    p.viewTriCount = r.viewTriCount.ptr;
+    p.viewTriStride = stride;
     p.instPos = r.instPos.ptr;
     p.instRot = r.instRot.ptr;
     p.instScale = r.instScale.ptr;
@@ -291,10 +309,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         p.toLight[c] = (float)(-kLightDir[c] / ln);
     p.ambient = kAmbient;
     p.diffuse = kDiffuse;
-    p.defaultColor[0] = p.defaultColor[1] = p.defaultColor[2] = p.defaultColor[3] = 1.0f;
     p.transposed = rt ? 1 : 0;
     // Raytracer ids are the segmask unless the caller asked for visibility ids
     p.idsAreSegmask = (rt && !(cfg.flags & MRX_FLAG_VISIBILITY_IDS)) ? 1 : 0;
+    p.debugSkip = 0;
+    if (const char *dbg = std::getenv("MRX_DEBUG_SKIP"))
+        p.debugSkip = (uint32_t)std::atoi(dbg);
 
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;
@@ -302,7 +322,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     inf.num_instances = (uint32_t)instObj.size();
     inf.num_objects = (uint32_t)r.objFirst.size();
     inf.num_triangles = (uint32_t)tris.size();
-    inf.num_materials = (uint32_t)mats.size();
+    inf.num_materials = cfg.num_materials;
     inf.num_textures = (uint32_t)texDescs.size();
     inf.max_world_triangles = maxWorldTris;
     inf.storage_fast = nfast;

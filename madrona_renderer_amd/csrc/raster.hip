@@ -29,9 +29,16 @@ constexpr int kCold = 12;        // dwords: u/v planes, lit colour
 constexpr int kBandRows = 16;    // a band is 64 x 16 pixels = 16 blocks of 8x8
 constexpr int kBlocksPerBand = 16;
 
+// Per-wave LDS: the shading record of each triangle of the chunk.  The brute
+// variant also parks the planes here (hot[0..11]); the strip variant keeps
+// them in registers and uses the compact layout.
 struct WaveLds {
-    float hot[kChunk][kHot];
+    float hot[kChunk][kHot];     // [0..11] planes (brute only), [12..15] shade
     float cold[kChunk][kCold];
+};
+struct WaveLdsCompact {
+    float shade[kChunk][4];      // rgba, texture, objectID, world-local index
+    float cold[kChunk][kCold];   // u/v planes, lit colour
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az,
@@ -72,11 +79,22 @@ struct ViewConst {
     float lv[3];
 };
 
-// S3-S7 for one world-triangle.  Writes the LDS record, returns validity.
+// Edge planes (inside <=> all >= 0) and the 1/depth plane of one triangle, as
+// functions of the storage pixel: value = fl(A*x + fl(B*y + C)).
+struct TriPlanes {
+    float A0, B0, C0, A1, B1, C1, A2, B2, C2, Dx, Dy, Dc;
+    // conservative bounds of the covered storage pixels (+-inf when a vertex
+    // is not safely in front of the eye); binning aid only, never decides a pixel
+    float bbX0, bbX1, bbY0, bbY1;
+};
+
+// S3-S7 for one world-triangle.  Planes are returned in registers; the shading
+// record goes to LDS (shade: rgba, texture, objectID, world-local index; cold:
+// u/v planes and lit colour).  Returns validity.
 __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
                                               const ViewConst &vc,
                                               WorldTri wt, int32_t kWorld,
-                                              float *hot, float *cold)
+                                              TriPlanes &out, float *shade, float *cold)
 {
     const uint32_t i = wt.inst;
     const float tx = p.instPos[3 * i + 0], ty = p.instPos[3 * i + 1],
@@ -105,11 +123,13 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     for (int r = 0; r < 3; ++r)
         tv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r], dt[0], dt[1], dt[2]);
 
+    __builtin_amdgcn_sched_barrier(0);
     const float4 *src = reinterpret_cast<const float4 *>(p.tris + wt.tri);
     const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+    const float4 mc = *reinterpret_cast<const float4 *>(p.triMats[wt.tri].color);
+    const int32_t tex = p.triMats[wt.tri].tex;
     const float op[9] = { t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x };
     const float uv[6] = { t2.y, t2.z, t2.w, t3.x, t3.y, t3.z };
-    const int32_t mat = __float_as_int(t3.w);
 
     float P[3][3];
 #pragma unroll
@@ -119,6 +139,7 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
             P[j][r] = dot3(MV[r][0], MV[r][1], MV[r][2],
                            op[3 * j], op[3 * j + 1], op[3 * j + 2]) + tv[r];
 
+    __builtin_amdgcn_sched_barrier(0);
     float N[3][3], e1[3], e2[3], nn[3];
     cross3(P[1], P[2], N[0]);
     cross3(P[2], P[0], N[1]);
@@ -131,9 +152,38 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     cross3(e1, e2, nn);
     const float d = dot3(nn[0], nn[1], nn[2], P[0][0], P[0][1], P[0][2]);
     const bool valid = fabsf(d) > 0.0f;                       // S6
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Binning aid: pixel-space bounding box of the projected vertices, padded
+    // by a pixel plus a relative margin that swallows the rounding of the
+    // approximate reciprocals here and of the plane evaluation.
+    {
+        const float wmin = fminf(fminf(P[0][1], P[1][1]), P[2][1]);
+        const float isx = __builtin_amdgcn_rcpf(p.sx), isz = __builtin_amdgcn_rcpf(p.sz);
+        float fx[3], fz[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float iw = __builtin_amdgcn_rcpf(P[j][1]);
+            fx[j] = (P[j][0] * iw - p.ox) * isx;   // image x in pixels
+            fz[j] = (P[j][2] * iw - p.oz) * isz;   // image y in pixels
+        }
+        float x0 = fminf(fminf(fx[0], fx[1]), fx[2]), x1 = fmaxf(fmaxf(fx[0], fx[1]), fx[2]);
+        float z0 = fminf(fminf(fz[0], fz[1]), fz[2]), z1 = fmaxf(fmaxf(fz[0], fz[1]), fz[2]);
+        const float mx = 1.0f + 8e-6f * fmaxf(fabsf(x0), fabsf(x1));
+        const float mz = 1.0f + 8e-6f * fmaxf(fabsf(z0), fabsf(z1));
+        x0 -= mx; x1 += mx; z0 -= mz; z1 += mz;
+        const bool ok = wmin > 1e-6f && (x1 - x0) < 3.0e38f && (z1 - z0) < 3.0e38f;
+        const float inf = __builtin_inff();
+        const bool trs = p.transposed != 0;
+        out.bbX0 = ok ? (trs ? z0 : x0) : -inf;
+        out.bbX1 = ok ? (trs ? z1 : x1) : inf;
+        out.bbY0 = ok ? (trs ? x0 : z0) : -inf;
+        out.bbY1 = ok ? (trs ? x1 : z1) : inf;
+    }
     const float flip = d < 0.0f ? -1.0f : 1.0f;
     const bool tr = p.transposed != 0;
 
+    __builtin_amdgcn_sched_barrier(0);
     float A[3], B[3], C[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
@@ -143,17 +193,17 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
         A[e] = (tr ? az : ax) * flip;
         B[e] = (tr ? ax : az) * flip;
         C[e] = cc * flip;
-        hot[3 * e + 0] = A[e];
-        hot[3 * e + 1] = B[e];
-        hot[3 * e + 2] = C[e];
     }
+    out.A0 = A[0]; out.B0 = B[0]; out.C0 = C[0];
+    out.A1 = A[1]; out.B1 = B[1]; out.C1 = C[1];
+    out.A2 = A[2]; out.B2 = B[2]; out.C2 = C[2];
     const float rd = 1.0f / d;
     {
         const float ax = (nn[0] * p.sx) * rd;
         const float az = (nn[2] * p.sz) * rd;
-        hot[9] = tr ? az : ax;
-        hot[10] = tr ? ax : az;
-        hot[11] = ((nn[0] * p.ox + nn[1]) + nn[2] * p.oz) * rd;
+        out.Dx = tr ? az : ax;
+        out.Dy = tr ? ax : az;
+        out.Dc = ((nn[0] * p.ox + nn[1]) + nn[2] * p.oz) * rd;
     }
     const float rad = fabsf(rd);
     cold[0] = ((uv[0] * A[0] + uv[2] * A[1]) + uv[4] * A[2]) * rad;
@@ -163,28 +213,20 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     cold[4] = ((uv[1] * B[0] + uv[3] * B[1]) + uv[5] * B[2]) * rad;
     cold[5] = ((uv[1] * C[0] + uv[3] * C[1]) + uv[5] * C[2]) * rad;
 
+    __builtin_amdgcn_sched_barrier(0);
     // S7: flat two-sided Lambert
     const float len = sqrtf(dot3(nn[0], nn[1], nn[2], nn[0], nn[1], nn[2]));
     float ndl = dot3(nn[0], nn[1], nn[2], vc.lv[0], vc.lv[1], vc.lv[2]) / len;
     if (d > 0.0f)
         ndl = -ndl;
     const float lit = p.ambient + p.diffuse * fmaxf(ndl, 0.0f);
-    float col[3] = { p.defaultColor[0], p.defaultColor[1], p.defaultColor[2] };
-    int32_t tex = -1;
-    if (mat >= 0 && (uint32_t)mat < p.numMaterials) {
-        const float4 mc = *reinterpret_cast<const float4 *>(p.materials[mat].color);
-        col[0] = mc.x; col[1] = mc.y; col[2] = mc.z;
-        tex = p.materials[mat].tex;
-    }
-    if (tex < 0 || (uint32_t)tex >= p.numTextures)
-        tex = -1;
-    const float l0 = lit * col[0], l1 = lit * col[1], l2 = lit * col[2];
+    const float l0 = lit * mc.x, l1 = lit * mc.y, l2 = lit * mc.z;
     cold[6] = l0; cold[7] = l1; cold[8] = l2;
     const uint32_t rgba = toU8(l0) | (toU8(l1) << 8) | (toU8(l2) << 16) | 0xFF000000u;
-    hot[12] = __uint_as_float(rgba);
-    hot[13] = __int_as_float(tex);
-    hot[14] = __int_as_float(obj);
-    hot[15] = __int_as_float(kWorld);
+    shade[0] = __uint_as_float(rgba);
+    shade[1] = __int_as_float(tex);
+    shade[2] = __int_as_float(obj);
+    shade[3] = __int_as_float(kWorld);
     return valid;
 }
 
@@ -230,11 +272,10 @@ struct TileCtx {
     int lx, ly;
 };
 
-__device__ __forceinline__ bool tileSetup(const RasterParams &p, int wave, int lane,
+__device__ __forceinline__ bool tileSetup(const RasterParams &p, uint32_t item, int lane,
                                           TileCtx &t, ViewConst &vc)
 {
     const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
-    const uint32_t item = blockIdx.x * kWavesPerBlock + wave;
     if (item >= p.numViews * tilesPerView)
         return false;
     t.view = item / tilesPerView;
@@ -249,9 +290,18 @@ __device__ __forceinline__ bool tileSetup(const RasterParams &p, int wave, int l
         vc.lv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r],
                         p.toLight[0], p.toLight[1], p.toLight[2]);
     }
-    const uint32_t world = p.viewWorld[t.view];
-    t.triBegin = p.worldTriStart[world];
-    t.numTris = p.worldTriStart[world + 1] - t.triBegin;
+    // wave-uniform: park the view constants in SGPRs
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            vc.Rc[r][cc] = __uint_as_float(
+                __builtin_amdgcn_readfirstlane(__float_as_uint(vc.Rc[r][cc])));
+        vc.c[r] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(vc.c[r])));
+        vc.lv[r] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(vc.lv[r])));
+    }
+    t.triBegin = t.view * p.viewTriStride;
+    t.numTris = p.viewTriCount[t.view];
     t.lx = lane & 7;
     t.ly = lane >> 3;
     return true;
@@ -265,8 +315,14 @@ __device__ __forceinline__ uint64_t setupChunk(const RasterParams &p, const View
     bool valid = false;
     const uint32_t k = chunk + lane;
     if (k < t.numTris) {
-        const WorldTri wt = p.worldTris[t.triBegin + k];
-        valid = setupTriangle(p, vc, wt, (int32_t)k, L.hot[lane], L.cold[lane]);
+        const WorldTri wt = p.viewTris[t.triBegin + k];
+        TriPlanes c;
+        float *h = L.hot[lane];
+        valid = setupTriangle(p, vc, wt, (int32_t)k, c, h + 12, L.cold[lane]);
+        h[0] = c.A0; h[1] = c.B0; h[2] = c.C0;
+        h[3] = c.A1; h[4] = c.B1; h[5] = c.C1;
+        h[6] = c.A2; h[7] = c.B2; h[8] = c.C2;
+        h[9] = c.Dx; h[10] = c.Dy; h[11] = c.Dc;
     }
     const uint64_t mask = __ballot(valid);
     waveLdsSync();
@@ -274,20 +330,23 @@ __device__ __forceinline__ uint64_t setupChunk(const RasterParams &p, const View
 }
 
 // Winner lookup + shading of one pixel (lane) of block b.
-template <bool IDS>
-__device__ __forceinline__ void resolvePixel(const RasterParams &p, const WaveLds &L,
+__device__ __forceinline__ const float *shadeRec(const WaveLds &L, int32_t w) { return &L.hot[w][12]; }
+__device__ __forceinline__ const float *shadeRec(const WaveLdsCompact &L, int32_t w) { return L.shade[w]; }
+
+template <bool IDS, typename LDS>
+__device__ __forceinline__ void resolvePixel(const RasterParams &p, const LDS &L,
                                              int32_t w, float bestInv, float px, float py,
                                              uint32_t &rgba, int32_t &id)
 {
-    const float *h = L.hot[w];
-    rgba = __float_as_uint(h[12]);
-    const int32_t tex = __float_as_int(h[13]);
+    const float *h = shadeRec(L, w);
+    rgba = __float_as_uint(h[0]);
+    const int32_t tex = __float_as_int(h[1]);
     if (tex >= 0) {
         const float tt = 1.0f / bestInv;
         rgba = shadeTextured(p, L.cold[w], tex, px, py, tt);
     }
     if (IDS)
-        id = __float_as_int(p.idsAreSegmask ? h[14] : h[15]);
+        id = __float_as_int(p.idsAreSegmask ? h[2] : h[3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -335,7 +394,7 @@ void rasterBruteKernel(const RasterParams p)
     const int lane = threadIdx.x % kWave;
     TileCtx t;
     ViewConst vc;
-    if (!tileSetup(p, wave, lane, t, vc))
+    if (!tileSetup(p, blockIdx.x * kWavesPerBlock + wave, lane, t, vc))
         return;
     WaveLds &L = lds[wave];
 
@@ -406,26 +465,352 @@ void rasterBruteKernel(const RasterParams p)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 0 ("strip"): wave-level binning in registers.
+//
+// Lane k keeps triangle k's twelve plane coefficients in VGPRs after setup and
+// classifies the tile's sixteen 32x8-pixel regions against them (in-lane loop,
+// all triangles of the chunk at once): a region is dropped for the triangle
+// when one edge plane is negative, or the 1/depth plane is outside
+// (invFar, invNear], at the region pixel where that plane is largest /
+// smallest.  The planes are evaluated as fl(A*x + fl(B*y + C)), monotone in x
+// and in y, so the extreme over a region is the value at one of its corner
+// pixels and dropping the region cannot change any pixel: classification only
+// skips work.  The raster loop then runs per 64x16 band over the triangles
+// whose mask touches the band (ballot), pulls the coefficients of triangle k
+// into SGPRs with v_readlane (no LDS round trip) and rasterises the surviving
+// regions as straight-line code, four 8x8 blocks at a time, lane = pixel.
+// ---------------------------------------------------------------------------
+// S3-S7 for the lane's triangle; planes stay in registers, the shading record
+// goes to LDS.  Returns validity.
+__device__ __forceinline__ bool setupLane(const RasterParams &p, const ViewConst &vc,
+                                          const TileCtx &t, uint32_t chunk, int lane,
+                                          WaveLdsCompact &L, TriPlanes &c)
+{
+    bool valid = false;
+    const uint32_t k = chunk + lane;
+    c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
+    c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
+    c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
+    if (k < t.numTris && !(p.debugSkip & 8u)) {
+        const WorldTri wt = p.viewTris[t.triBegin + k];
+        valid = setupTriangle(p, vc, wt, (int32_t)k, c, L.shade[lane], L.cold[lane]);
+    }
+    return valid;
+}
+
+// Bits 0..15: the tile's 32x8 regions (bit 2*strip + half) the lane's triangle
+// can touch.  Bit 16: the 1/depth plane stays <= invNear over the whole tile,
+// so the per-pixel near test can be dropped for this triangle.
+constexpr uint32_t kNearFree = 1u << 16;
+
+__device__ __forceinline__ uint32_t classifyRegions(const TriPlanes &c, const TileCtx &t,
+                                                    float invNear, float invFar)
+{
+    const float X0 = (float)t.tileX0, Y0 = (float)t.tileY0;
+    // x / y of the region pixel where each plane is largest (depth: also smallest)
+    const float xa0 = c.A0 < 0.0f ? X0 : X0 + 31.0f;
+    const float xa1 = c.A1 < 0.0f ? X0 : X0 + 31.0f;
+    const float xa2 = c.A2 < 0.0f ? X0 : X0 + 31.0f;
+    const float xdh = c.Dx < 0.0f ? X0 : X0 + 31.0f;
+    const float xdl = c.Dx < 0.0f ? X0 + 31.0f : X0;
+    const float yb0 = c.B0 < 0.0f ? Y0 : Y0 + 7.0f;
+    const float yb1 = c.B1 < 0.0f ? Y0 : Y0 + 7.0f;
+    const float yb2 = c.B2 < 0.0f ? Y0 : Y0 + 7.0f;
+    const float ydh = c.Dy < 0.0f ? Y0 : Y0 + 7.0f;
+    const float ydl = c.Dy < 0.0f ? Y0 + 7.0f : Y0;
+    uint32_t mask = 0;
+    float dmax = -__builtin_inff();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float dy = (float)(8 * s);
+        const float r0 = __builtin_fmaf(c.B0, yb0 + dy, c.C0);
+        const float r1 = __builtin_fmaf(c.B1, yb1 + dy, c.C1);
+        const float r2 = __builtin_fmaf(c.B2, yb2 + dy, c.C2);
+        const float rh = __builtin_fmaf(c.Dy, ydh + dy, c.Dc);
+        const float rl = __builtin_fmaf(c.Dy, ydl + dy, c.Dc);
+        const bool yin = (Y0 + dy + 7.0f >= c.bbY0) && (Y0 + dy <= c.bbY1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float dx = (float)(32 * hf);
+            const float e0 = __builtin_fmaf(c.A0, xa0 + dx, r0);
+            const float e1 = __builtin_fmaf(c.A1, xa1 + dx, r1);
+            const float e2 = __builtin_fmaf(c.A2, xa2 + dx, r2);
+            const float dh = __builtin_fmaf(c.Dx, xdh + dx, rh);
+            const float dl = __builtin_fmaf(c.Dx, xdl + dx, rl);
+            const bool xin = (X0 + dx + 31.0f >= c.bbX0) && (X0 + dx <= c.bbX1);
+            const bool possible = (fminf(fminf(e0, e1), e2) >= 0.0f) &&
+                                  (dh > invFar) && (dl <= invNear) && xin && yin;
+            mask |= possible ? (1u << (2 * s + hf)) : 0u;
+            dmax = fmaxf(dmax, dh);
+        }
+    }
+    if (dmax <= invNear)
+        mask |= kNearFree;
+    return mask;
+}
+
+constexpr int kRegionBlocks = 4;    // a region is 32 x 8 pixels = 4 blocks of 8x8
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed f32 FMA: two independent, individually rounded fmaf()s in one
+// v_pk_fma_f32 (plain v_fma_f32 issues at half the packed rate on gfx950).
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c)
+{
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+// Planes of one triangle as the raster loop wants them: pairs that share a
+// multiplier sit in adjacent registers.  LDS layout of TileLds::planes[k]:
+//   [0..3] A0 A1 A2 Dx   [4..7] B0 B1 B2 Dy   [8..11] C0 C1 C2 Dc   [12] mask
+struct PlanePairs {
+    f32x2 A01, A2D, B01, B2D, C01, C2D;
+};
+
+__device__ __forceinline__ PlanePairs loadPlanes(const float (*planes)[16], int k)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(planes[k]);
+    const float4 a = src[0], b = src[1], c = src[2];
+    PlanePairs q;
+    q.A01 = f32x2{ a.x, a.y }; q.A2D = f32x2{ a.z, a.w };
+    q.B01 = f32x2{ b.x, b.y }; q.B2D = f32x2{ b.z, b.w };
+    q.C01 = f32x2{ c.x, c.y }; q.C2D = f32x2{ c.z, c.w };
+    return q;
+}
+
+// One pixel (lane) of one block against one triangle.
+template <bool NEAR>
+__device__ __forceinline__ void pixelTest(const PlanePairs &q, f32x2 r01, f32x2 r2d, float px,
+                                          float invNear, int32_t kv, float &best, int32_t &bid)
+{
+    const f32x2 pp = { px, px };
+    const f32x2 e01 = fma2(q.A01, pp, r01);       // e0, e1
+    const f32x2 e2d = fma2(q.A2D, pp, r2d);       // e2, 1/depth
+    float cand = (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f) ? e2d.y : best;
+    if (NEAR)
+        cand = (cand <= invNear) ? cand : best;
+    const bool win = cand > best;
+    best = win ? cand : best;
+    bid = win ? kv : bid;
+}
+
+// Rasterise one 32x8 region against the triangles in `act` (bit k = triangle
+// k of the chunk survives classification for this region), in triangle order.
+// Triangle planes are broadcast from LDS (all lanes read the same 48 bytes).
+template <bool NEAR>
+__device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t act,
+                                             const float (&px)[kRegionBlocks], float py,
+                                             float invNear,
+                                             float (&best)[kRegionBlocks],
+                                             int32_t (&bid)[kRegionBlocks])
+{
+    const f32x2 yy = { py, py };
+    for (; act != 0; act &= act - 1) {
+        const int k = __builtin_ctzll(act);
+        const PlanePairs q = loadPlanes(planes, k);
+        const f32x2 r01 = fma2(q.B01, yy, q.C01);
+        const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b)
+            pixelTest<NEAR>(q, r01, r2d, px[b], invNear, k, best[b], bid[b]);
+    }
+}
+
+// Shade + store a region.  A lane owns four consecutive pixels of one row
+// (pixel b of the lane is x = fx0 + b), so the common case is one 16-byte store
+// per output tensor per lane: eight lanes fill a 128-byte line, the wave writes
+// the region's 1 KiB of RGBA8 (and of depth) with a single instruction each.
+template <bool IDS, bool RESOLVED>
+__device__ __forceinline__ void outputRegion(const RasterParams &p, const WaveLdsCompact &L,
+                                             const TileCtx &t, uint32_t fx0, uint32_t fy,
+                                             const float (&px)[kRegionBlocks], float py,
+                                             float invFar, const float (&best)[kRegionBlocks],
+                                             const int32_t (&bid)[kRegionBlocks],
+                                             const uint32_t (&preRgba)[kRegionBlocks],
+                                             const int32_t (&preId)[kRegionBlocks])
+{
+    uint32_t rgba[kRegionBlocks];
+    int32_t id[kRegionBlocks];
+    float dep[kRegionBlocks];
+#pragma unroll
+    for (int b = 0; b < kRegionBlocks; ++b) {
+        rgba[b] = 0xFF000000u;
+        id[b] = -1;
+        if (RESOLVED) {
+            rgba[b] = preRgba[b];
+            id[b] = preId[b];
+        } else if (bid[b] >= 0) {
+            resolvePixel<IDS>(p, L, bid[b], best[b], px[b], py, rgba[b], id[b]);
+        }
+        // depth = 1/best: v_rcp_f32 (<= 1 ulp); the colour path uses the
+        // correctly rounded quotient where texel choice depends on it
+        dep[b] = best[b] > invFar ? __builtin_amdgcn_rcpf(best[b]) : 0.0f;
+    }
+    if (fy >= p.nslow || (p.debugSkip & 1u))
+        return;
+    const size_t o = ((size_t)t.view * p.nslow + fy) * p.nfast + fx0;
+    if ((p.nfast & 3u) == 0 && fx0 + 3 < p.nfast) {
+        *reinterpret_cast<uint4 *>(p.rgb + o) = make_uint4(rgba[0], rgba[1], rgba[2], rgba[3]);
+        *reinterpret_cast<float4 *>(p.depth + o) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        if (IDS)
+            *reinterpret_cast<int4 *>(p.ids + o) = make_int4(id[0], id[1], id[2], id[3]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            if (fx0 + b < p.nfast) {
+                p.rgb[o + b] = rgba[b];
+                p.depth[o + b] = dep[b];
+                if (IDS)
+                    p.ids[o + b] = id[b];
+            }
+        }
+    }
+}
+
+// One workgroup = one 64x64 tile.  Wave 0 sets up and classifies the chunk's
+// triangles (lane = triangle) and publishes planes + region mask in LDS; after
+// the barrier every wave rasterises its own two 64x8 strips (four regions),
+// broadcasting triangle k's planes from LDS per visit, so the tile's triangles
+// are set up once while four times as many waves are in flight.
+struct TileLds {
+    float planes[kChunk][16];    // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | mask
+    WaveLdsCompact rec;          // shading records
+};
+
+template <bool IDS, bool MULTI>
+__global__ __launch_bounds__(kWave *kWavesPerBlock, MULTI ? 3 : 8)
+void rasterStripKernel(const RasterParams p)
+{
+    __shared__ TileLds lds;
+    const int wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    TileCtx t;
+    ViewConst vc;
+    if (!tileSetup(p, blockIdx.x, lane, t, vc))
+        return;                                   // whole workgroup leaves together
+    const float invNear = p.invNear, invFar = p.invFar;
+    const uint32_t dummyRgba[kRegionBlocks] = { 0, 0, 0, 0 };
+    const int32_t dummyId[kRegionBlocks] = { 0, 0, 0, 0 };
+
+    // per-wave pixel state: strips 2*wave and 2*wave+1, two regions each
+    float best[4][kRegionBlocks];
+    int32_t bid[4][kRegionBlocks];
+    uint32_t outRgba[4][kRegionBlocks];
+    int32_t outId[4][kRegionBlocks];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            best[g][b] = invFar;
+            bid[g][b] = -1;
+            outRgba[g][b] = 0xFF000000u;
+            outId[g][b] = -1;
+        }
+
+    for (uint32_t chunk = 0; chunk == 0 || chunk < t.numTris; chunk += kChunk) {
+        if (MULTI && chunk != 0)
+            __syncthreads();                      // previous chunk fully consumed
+        if (wave == 0) {
+            TriPlanes c;
+            uint32_t mask = 0;
+            const bool valid = setupLane(p, vc, t, chunk, lane, lds.rec, c);
+            if (valid && !(p.debugSkip & 4u))
+                mask = classifyRegions(c, t, invNear, invFar);
+            float4 *dst = reinterpret_cast<float4 *>(lds.planes[lane]);
+            dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
+            dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
+            dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
+            dst[3] = make_float4(__uint_as_float(mask), 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        // lane k looks at triangle k's region mask; planes are read per visit
+        const uint32_t mask = __float_as_uint(lds.planes[lane][12]);
+        // every surviving triangle stays behind the near plane over the whole
+        // tile: the per-pixel near test is dropped
+        const bool nearFree = __ballot(mask != 0 && !(mask & kNearFree)) == 0;
+
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int strip = 2 * wave + (g >> 1), hf = g & 1;
+            const uint32_t fy = t.tileY0 + strip * 8 + t.ly;
+            const float py = (float)fy;
+            const uint32_t fx0 = t.tileX0 + hf * 32 + 4 * t.lx;
+            float px[kRegionBlocks];
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b)
+                px[b] = (float)(fx0 + b);
+            const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
+            if (!(p.debugSkip & 2u)) {
+                if (nearFree)
+                    rasterRegion<false>(lds.planes, act, px, py, invNear, best[g], bid[g]);
+                else
+                    rasterRegion<true>(lds.planes, act, px, py, invNear, best[g], bid[g]);
+            }
+            if (MULTI) {
+                // shade this chunk's winners before its records are replaced
+#pragma unroll
+                for (int b = 0; b < kRegionBlocks; ++b) {
+                    if (bid[g][b] >= 0)
+                        resolvePixel<IDS>(p, lds.rec, bid[g][b], best[g][b], px[b], py,
+                                          outRgba[g][b], outId[g][b]);
+                    bid[g][b] = -1;
+                }
+            } else {
+                outputRegion<IDS, false>(p, lds.rec, t, fx0, fy, px, py, invFar, best[g], bid[g],
+                                         dummyRgba, dummyId);
+            }
+        }
+        if (!MULTI)
+            break;
+    }
+
+    if (MULTI) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int strip = 2 * wave + (g >> 1), hf = g & 1;
+            const uint32_t fy = t.tileY0 + strip * 8 + t.ly;
+            const uint32_t fx0 = t.tileX0 + hf * 32 + 4 * t.lx;
+            float px[kRegionBlocks];
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b)
+                px[b] = (float)(fx0 + b);
+            outputRegion<IDS, true>(p, lds.rec, t, fx0, fy, px, (float)fy, invFar, best[g], bid[g],
+                                    outRgba[g], outId[g]);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
                         int32_t variant, hipStream_t stream)
 {
-    (void)variant;
     const uint32_t items = p.numViews * p.tilesFast * p.tilesSlow;
     if (items == 0)
         return hipSuccess;
-    const dim3 grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
+    // brute: one wave per tile; strip: one workgroup per tile
+    const dim3 grid(variant == kVariantBrute ? (items + kWavesPerBlock - 1) / kWavesPerBlock
+                                             : items);
     const dim3 block(kWave * kWavesPerBlock);
     const bool ids = p.ids != nullptr;
     const bool multi = maxWorldTris > (uint32_t)kChunk;
-    if (ids) {
-        if (multi) rasterBruteKernel<true, true><<<grid, block, 0, stream>>>(p);
-        else       rasterBruteKernel<true, false><<<grid, block, 0, stream>>>(p);
-    } else {
-        if (multi) rasterBruteKernel<false, true><<<grid, block, 0, stream>>>(p);
-        else       rasterBruteKernel<false, false><<<grid, block, 0, stream>>>(p);
+#define MRX_LAUNCH(KERNEL)                                                     \
+    do {                                                                       \
+        if (ids) {                                                             \
+            if (multi) KERNEL<true, true><<<grid, block, 0, stream>>>(p);      \
+            else       KERNEL<true, false><<<grid, block, 0, stream>>>(p);     \
+        } else {                                                               \
+            if (multi) KERNEL<false, true><<<grid, block, 0, stream>>>(p);     \
+            else       KERNEL<false, false><<<grid, block, 0, stream>>>(p);    \
+        }                                                                      \
+    } while (0)
+    switch (variant) {
+    case kVariantBrute: MRX_LAUNCH(rasterBruteKernel); break;
+    default:            MRX_LAUNCH(rasterStripKernel); break;
     }
+#undef MRX_LAUNCH
     return hipGetLastError();
 }
 

@@ -15,12 +15,14 @@ struct alignas(16) ObjTri {
 };
 static_assert(sizeof(ObjTri) == 64, "ObjTri must be one 64-byte line");
 
-struct alignas(16) Material {
+// Material of one object triangle, resolved on the host (mesh material or the
+// default colour; texture index validated): one 32-byte record next to ObjTri.
+struct alignas(16) TriMat {
     float color[4];
     int32_t tex;     // texture index, -1 = untextured
     int32_t pad[3];
 };
-static_assert(sizeof(Material) == 32, "Material layout");
+static_assert(sizeof(TriMat) == 32, "TriMat layout");
 
 struct TexDesc {
     uint32_t offset;  // texel offset into the RGBA8 pool
@@ -37,14 +39,15 @@ struct WorldTri {
 struct RasterParams {
     // shared read-only scene
     const ObjTri *tris;
-    const Material *materials;
+    const TriMat *triMats;           // parallel to tris
     const TexDesc *textures;
     const uint32_t *texels;          // RGBA8
-    uint32_t numMaterials, numTextures;
-    // per-world tables
-    const WorldTri *worldTris;
-    const uint32_t *worldTriStart;   // [worlds + 1]
-    const uint32_t *viewWorld;       // [views]
+    // per-view draw lists: view v draws viewTris[v * viewTriStride + k],
+    // k < viewTriCount[v] -- one load level between the view index and the
+    // triangle's pose / geometry rows
+    const WorldTri *viewTris;
+    const uint32_t *viewTriCount;    // [views]
+    uint32_t viewTriStride;
     // pose state (the exported, mutable tensors)
     const float *instPos;            // [I][3]
     const float *instRot;            // [I][4] w,x,y,z
@@ -64,9 +67,12 @@ struct RasterParams {
     float invNear, invFar;
     float toLight[3];
     float ambient, diffuse;
-    float defaultColor[4];
     int32_t transposed;              // Raytracer-mode [x][y] storage
     int32_t idsAreSegmask;           // ids buffer holds objectID instead of tri index
+    // Timing-only ablation switches (MRX_DEBUG_SKIP env, never set in
+    // production): 1 skip stores, 2 skip raster, 4 skip classification,
+    // 8 skip triangle setup.  Outputs are wrong when any bit is set.
+    uint32_t debugSkip;
 };
 
 // Kernel variants (mrx_config.kernel_variant).
