@@ -176,6 +176,10 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total);
 /*    mrx_mark(r, 0 | 1) records HIP event 0 / 1 on the renderer's stream;
  *    mrx_elapsed_ms waits for event 1 and returns event1 - event0.  They let a
  *    caller bracket its own timed region of mrx_step calls with device time. */
+/*    Diagnostic: with MRX_DEBUG_STAMPS=1 in the environment at mrx_create, the
+ *    kernels record per-wave timestamps; mrx_debug_stamps copies them out
+ *    ([workgroups][4 waves][8] u64, 100 MHz ticks). Returns the count copied. */
+int64_t mrx_debug_stamps(mrx_renderer *r, uint64_t *dst, int64_t capacity);
 int mrx_mark(mrx_renderer *r, int which);
 int mrx_elapsed_ms(mrx_renderer *r, float *ms);
 

@@ -91,6 +91,7 @@ struct mrx_renderer {
     DevBuf<uint32_t> rgb;
     DevBuf<float> depth;
     DevBuf<int32_t> ids;
+    DevBuf<unsigned long long> stamps;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~mrx_renderer()
@@ -100,7 +101,7 @@ struct mrx_renderer {
         viewTris.release(); viewTriCount.release();
         instPos.release(); instRot.release(); instScale.release();
         camPos.release(); camRot.release(); instObj.release();
-        rgb.release(); depth.release(); ids.release();
+        rgb.release(); depth.release(); ids.release(); stamps.release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
     }
@@ -315,6 +316,17 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.debugSkip = 0;
     if (const char *dbg = std::getenv("MRX_DEBUG_SKIP"))
         p.debugSkip = (uint32_t)std::atoi(dbg);
+    p.debugStamps = nullptr;
+    if (const char *dbg = std::getenv("MRX_DEBUG_STAMPS"))
+        if (std::atoi(dbg) != 0) {
+            const size_t n = (size_t)nviews * p.tilesFast * p.tilesSlow * 4 * 8;
+            MRX_HIP(r.stamps.alloc(n));
+            MRX_HIP(hipMemset(r.stamps.ptr, 0, n * sizeof(unsigned long long)));
+            p.debugStamps = r.stamps.ptr;
+        }
+    p.debugSlots = 0;
+    if (const char *dbg = std::getenv("MRX_DEBUG_SLOTS"))
+        p.debugSlots = std::atoi(dbg);
 
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;
@@ -527,6 +539,17 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
     MRX_HIP(hipEventSynchronize(r->ev1));
     MRX_HIP(hipEventElapsedTime(ms_total, r->ev0, r->ev1));
     return MRX_OK;
+}
+
+int64_t mrx_debug_stamps(mrx_renderer *r, uint64_t *dst, int64_t capacity)
+{
+    if (!r || !dst || !r->stamps.ptr)
+        return 0;
+    const int64_t n = (int64_t)r->stamps.count < capacity ? (int64_t)r->stamps.count : capacity;
+    if (hipSetDevice(r->device) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess ||
+        hipMemcpy(dst, r->stamps.ptr, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+    return n;
 }
 
 int mrx_mark(mrx_renderer *r, int which)

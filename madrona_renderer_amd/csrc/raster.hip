@@ -579,7 +579,9 @@ __device__ __forceinline__ PlanePairs loadPlanes(const float (*planes)[16], int 
     return q;
 }
 
-// One pixel (lane) of one block against one triangle.
+// One pixel of the lane against one triangle.  The three lane predicates are
+// combined on the scalar unit (s_and_b64), which runs beside the vector ALU
+// that bounds this kernel.
 template <bool NEAR>
 __device__ __forceinline__ void pixelTest(const PlanePairs &q, f32x2 r01, f32x2 r2d, float px,
                                           float invNear, int32_t kv, float &best, int32_t &bid)
@@ -587,18 +589,17 @@ __device__ __forceinline__ void pixelTest(const PlanePairs &q, f32x2 r01, f32x2 
     const f32x2 pp = { px, px };
     const f32x2 e01 = fma2(q.A01, pp, r01);       // e0, e1
     const f32x2 e2d = fma2(q.A2D, pp, r2d);       // e2, 1/depth
-    float cand = (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f) ? e2d.y : best;
+    bool in = (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f) & (e2d.y > best);
     if (NEAR)
-        cand = (cand <= invNear) ? cand : best;
-    const bool win = cand > best;
-    best = win ? cand : best;
-    bid = win ? kv : bid;
+        in = in & (e2d.y <= invNear);
+    best = in ? e2d.y : best;
+    bid = in ? kv : bid;
 }
 
 // Rasterise one 32x8 region against the triangles in `act` (bit k = triangle
 // k of the chunk survives classification for this region), in triangle order.
 // Triangle planes are broadcast from LDS (all lanes read the same 48 bytes).
-template <bool NEAR>
+template <bool NEAR, int IDSHIFT>
 __device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t act,
                                              const float (&px)[kRegionBlocks], float py,
                                              float invNear,
@@ -607,13 +608,15 @@ __device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t
 {
     const f32x2 yy = { py, py };
     for (; act != 0; act &= act - 1) {
-        const int k = __builtin_ctzll(act);
+        const int k = __builtin_ctzll(act);      // record index in the LDS tables
         const PlanePairs q = loadPlanes(planes, k);
         const f32x2 r01 = fma2(q.B01, yy, q.C01);
         const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
+        // the winner is tracked as k << IDSHIFT (group kernel: the byte offset
+        // of its shading record)
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b)
-            pixelTest<NEAR>(q, r01, r2d, px[b], invNear, k, best[b], bid[b]);
+            pixelTest<NEAR>(q, r01, r2d, px[b], invNear, k << IDSHIFT, best[b], bid[b]);
     }
 }
 
@@ -744,9 +747,9 @@ void rasterStripKernel(const RasterParams p)
             const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
             if (!(p.debugSkip & 2u)) {
                 if (nearFree)
-                    rasterRegion<false>(lds.planes, act, px, py, invNear, best[g], bid[g]);
+                    rasterRegion<false, 0>(lds.planes, act, px, py, invNear, best[g], bid[g]);
                 else
-                    rasterRegion<true>(lds.planes, act, px, py, invNear, best[g], bid[g]);
+                    rasterRegion<true, 0>(lds.planes, act, px, py, invNear, best[g], bid[g]);
             }
             if (MULTI) {
                 // shade this chunk's winners before its records are replaced
@@ -782,6 +785,283 @@ void rasterStripKernel(const RasterParams p)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 0, worlds of at most 64 triangles: one workgroup renders a group of
+// G = 64 / SLOTS consecutive tiles.  Wave 0 sets up and classifies the
+// triangles of all G tiles in ONE pass (lane = tile j, triangle slot k: dense
+// lanes instead of 14-of-64), publishes planes / masks / shading records in
+// LDS; after the barrier the four waves walk the G tiles, each wave rastering
+// its own two 64x8 strips of every tile.
+// ---------------------------------------------------------------------------
+constexpr int kBackground = kChunk;   // record index of "nothing hit"
+
+struct GroupLds {
+    float planes[kChunk][16];           // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | mask
+    float shade[kChunk + 1][4];         // rgba, texture, objectID, world-local index
+    float cold[kChunk][kCold];          // u/v planes, lit colour
+    uint32_t tileInfo[4][4];            // per tile of the group: view, x0, y0, flags
+    uint32_t nextItem;                  // (tile, strip) work counter of phase R
+};
+constexpr uint32_t kTileAnyTex = 1u, kTileNearFree = 2u, kTileValid = 4u;
+
+__device__ __forceinline__ const float *shadeRec(const GroupLds &L, int32_t w) { return L.shade[w]; }
+
+// Shade + store one region of a tile (group kernel).  `bid` is the byte offset
+// of the winner's shading record (the background has its own record, so the
+// lookup is unconditional); base pointers are wave-uniform.
+template <bool IDS, bool FULL>
+__device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLds &L,
+                                            uint32_t *rgbTile, float *depthTile, int32_t *idsTile,
+                                            uint32_t pixOff, uint32_t fx0, uint32_t fy,
+                                            bool anyTex, const float (&px)[kRegionBlocks], float py,
+                                            const float (&best)[kRegionBlocks],
+                                            const int32_t (&bid)[kRegionBlocks])
+{
+    uint32_t rgba[kRegionBlocks];
+    int32_t id[kRegionBlocks];
+    float dep[kRegionBlocks];
+    const char *shadeBase = reinterpret_cast<const char *>(&L.shade[0][0]);
+#pragma unroll
+    for (int b = 0; b < kRegionBlocks; ++b) {
+        const float *h = reinterpret_cast<const float *>(shadeBase + bid[b]);
+        rgba[b] = __float_as_uint(h[0]);
+        if (IDS)
+            id[b] = __float_as_int(p.idsAreSegmask ? h[2] : h[3]);
+        // depth = 1/best: v_rcp_f32 (<= 1 ulp); textured colour below uses the
+        // correctly rounded quotient because texel choice depends on it
+        dep[b] = bid[b] != kBackground * 16 ? __builtin_amdgcn_rcpf(best[b]) : 0.0f;
+    }
+    if (anyTex) {
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            const int32_t rec = bid[b] >> 4;
+            const int32_t tex = __float_as_int(L.shade[rec][1]);
+            if (tex >= 0)
+                rgba[b] = shadeTextured(p, L.cold[rec], tex, px[b], py, 1.0f / best[b]);
+        }
+    }
+    if (p.debugSkip & 1u)
+        return;
+    if (FULL) {
+        *reinterpret_cast<uint4 *>(rgbTile + pixOff) = make_uint4(rgba[0], rgba[1], rgba[2], rgba[3]);
+        *reinterpret_cast<float4 *>(depthTile + pixOff) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        if (IDS)
+            *reinterpret_cast<int4 *>(idsTile + pixOff) = make_int4(id[0], id[1], id[2], id[3]);
+    } else if (fy < p.nslow) {
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            if (fx0 + b < p.nfast) {
+                rgbTile[pixOff + b] = rgba[b];
+                depthTile[pixOff + b] = dep[b];
+                if (IDS)
+                    idsTile[pixOff + b] = id[b];
+            }
+        }
+    }
+}
+
+// A region no triangle can touch: background everywhere, no per-pixel work.
+template <bool IDS, bool FULL>
+__device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t *rgbTile,
+                                                float *depthTile, int32_t *idsTile,
+                                                uint32_t pixOff, uint32_t fx0, uint32_t fy)
+{
+    if (p.debugSkip & 1u)
+        return;
+    const uint32_t bg = 0xFF000000u;
+    if (FULL) {
+        *reinterpret_cast<uint4 *>(rgbTile + pixOff) = make_uint4(bg, bg, bg, bg);
+        *reinterpret_cast<float4 *>(depthTile + pixOff) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (IDS)
+            *reinterpret_cast<int4 *>(idsTile + pixOff) = make_int4(-1, -1, -1, -1);
+    } else if (fy < p.nslow) {
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            if (fx0 + b < p.nfast) {
+                rgbTile[pixOff + b] = bg;
+                depthTile[pixOff + b] = 0.0f;
+                if (IDS)
+                    idsTile[pixOff + b] = -1;
+            }
+        }
+    }
+}
+
+template <bool IDS, int SLOTS>
+__global__ __launch_bounds__(kWave *kWavesPerBlock, 4)
+void rasterGroupKernel(const RasterParams p)
+{
+    constexpr int G = kChunk / SLOTS;
+    __shared__ GroupLds lds;
+    const int wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
+    const uint32_t numItems = p.numViews * tilesPerView;
+    const uint32_t item0 = blockIdx.x * G;
+    const float invNear = p.invNear, invFar = p.invFar;
+    unsigned long long *stamps = p.debugStamps
+        ? p.debugStamps + ((size_t)blockIdx.x * kWavesPerBlock + wave) * 8 : nullptr;
+#define MRX_STAMP(i)                                                           \
+    do {                                                                       \
+        if (stamps && lane == 0)                                               \
+            stamps[i] = __builtin_amdgcn_s_memrealtime();                      \
+    } while (0)
+    MRX_STAMP(0);
+
+    // ---- S: wave 0, lane = (tile j of the group, triangle slot k)
+    if (wave == 0) {
+        const int j = lane / SLOTS, k = lane % SLOTS;
+        const uint32_t item = item0 + j;
+        const bool tileOk = item < numItems;
+        TileCtx t;
+        t.view = tileOk ? (tilesPerView == 1 ? item : item / tilesPerView) : 0u;
+        const uint32_t tile = tilesPerView == 1 ? 0u : item - t.view * tilesPerView;
+        t.tileX0 = (tile % p.tilesFast) * 64u;
+        t.tileY0 = (tile / p.tilesFast) * 64u;
+        t.triBegin = t.view * p.viewTriStride;
+        t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
+        t.lx = t.ly = 0;
+        ViewConst vc;
+        {
+            const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * t.view);
+            quatToMat(q.x, q.y, q.z, q.w, vc.Rc);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                vc.c[r] = p.camPos[3 * t.view + r];
+                vc.lv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r],
+                                p.toLight[0], p.toLight[1], p.toLight[2]);
+            }
+        }
+        TriPlanes c;
+        c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
+        c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
+        c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
+        bool valid = false;
+        lds.shade[lane][1] = __int_as_float(-1);
+        MRX_STAMP(1);
+        if ((uint32_t)k < t.numTris && !(p.debugSkip & 8u)) {
+            const WorldTri wt = p.viewTris[t.triBegin + k];
+            valid = setupTriangle(p, vc, wt, k, c, lds.shade[lane], lds.cold[lane]);
+        }
+        MRX_STAMP(2);
+        uint32_t mask = 0;
+        if (valid && !(p.debugSkip & 4u))
+            mask = classifyRegions(c, t, invNear, invFar);
+        MRX_STAMP(3);
+        float4 *dst = reinterpret_cast<float4 *>(lds.planes[lane]);
+        dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
+        dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
+        dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
+        dst[3] = make_float4(__uint_as_float(mask), 0.f, 0.f, 0.f);
+        // per-tile flags from sub-ballots of the tile's SLOTS lanes
+        const uint64_t slotBits = SLOTS == 64 ? ~0ull : ((1ull << SLOTS) - 1ull);
+        const uint64_t texB = __ballot(mask != 0 && __float_as_int(lds.shade[lane][1]) >= 0);
+        const uint64_t nearB = __ballot(mask != 0 && !(mask & kNearFree));
+        if (k == 0) {
+            uint32_t fl = tileOk ? kTileValid : 0u;
+            if ((texB >> (j * SLOTS)) & slotBits) fl |= kTileAnyTex;
+            if (((nearB >> (j * SLOTS)) & slotBits) == 0) fl |= kTileNearFree;
+            lds.tileInfo[j][0] = t.view;
+            lds.tileInfo[j][1] = t.tileX0;
+            lds.tileInfo[j][2] = t.tileY0;
+            lds.tileInfo[j][3] = fl;
+        }
+        if (lane == 0) {
+            lds.nextItem = 0;
+            lds.shade[kBackground][0] = __uint_as_float(0xFF000000u);
+            lds.shade[kBackground][1] = __int_as_float(-1);
+            lds.shade[kBackground][2] = __int_as_float(-1);
+            lds.shade[kBackground][3] = __int_as_float(-1);
+        }
+    }
+    __syncthreads();
+    MRX_STAMP(4);
+
+    // ---- R + O: the four waves pull (tile, strip) work items off an LDS
+    //      counter -- strips differ a lot in cost (sky vs. ground vs. objects),
+    //      a static split leaves waves idle
+    const int lx = lane & 7, ly = lane >> 3;
+    const uint32_t laneOff = (uint32_t)ly * p.nfast + 4u * lx;
+    int cachedTile = -1;
+    uint32_t view = 0, tileX0 = 0, tileY0 = 0, mask = 0;
+    float pxTile[2][kRegionBlocks] = {};
+    bool anyTex = false, nearFree = false, full = false;
+    uint32_t *rgbTile = nullptr;
+    float *depthTile = nullptr;
+    int32_t *idsTile = nullptr;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0)
+            item = atomicAdd(&lds.nextItem, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= (uint32_t)(G * 8))
+            break;
+        const int j = (int)(item >> 3), strip = (int)(item & 7u);
+        if (j != cachedTile) {
+            cachedTile = j;
+            const uint32_t flags = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][3]);
+            if (!(flags & kTileValid))
+                break;                              // tiles past the end of the batch
+            view = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][0]);
+            tileX0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][1]);
+            tileY0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][2]);
+            anyTex = flags & kTileAnyTex;
+            nearFree = flags & kTileNearFree;
+            const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
+            rgbTile = p.rgb + tileBase;
+            depthTile = p.depth + tileBase;
+            idsTile = IDS ? p.ids + tileBase : nullptr;
+            full = (p.nfast & 3u) == 0 && tileX0 + 64u <= p.nfast && tileY0 + 64u <= p.nslow;
+            // lane k < SLOTS looks at the region mask of triangle slot k of tile j
+            mask = lane < SLOTS ? __float_as_uint(lds.planes[j * SLOTS + lane][12]) : 0u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int b = 0; b < kRegionBlocks; ++b)
+                    pxTile[hf][b] = (float)(tileX0 + hf * 32 + 4 * lx + b);
+        }
+        const uint32_t fy = tileY0 + strip * 8 + ly;
+        const float py = (float)fy;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
+            const uint32_t pixOff = (uint32_t)(strip * 8) * p.nfast + hf * 32 + laneOff;
+            // bit (j*SLOTS + k): record index of a surviving triangle
+            const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u) << (j * SLOTS);
+            if (act == 0) {
+                if (full)
+                    storeBackground<IDS, true>(p, rgbTile, depthTile, idsTile, pixOff, fx0, fy);
+                else
+                    storeBackground<IDS, false>(p, rgbTile, depthTile, idsTile, pixOff, fx0, fy);
+                continue;
+            }
+            const float (&px)[kRegionBlocks] = pxTile[hf];
+            float best[kRegionBlocks];
+            int32_t bid[kRegionBlocks];
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b) {
+                best[b] = invFar;
+                bid[b] = kBackground * 16;
+            }
+            if (!(p.debugSkip & 2u)) {
+                if (nearFree)
+                    rasterRegion<false, 4>(lds.planes, act, px, py, invNear, best, bid);
+                else
+                    rasterRegion<true, 4>(lds.planes, act, px, py, invNear, best, bid);
+            }
+            if (full)
+                storeRegion<IDS, true>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy, anyTex,
+                                       px, py, best, bid);
+            else
+                storeRegion<IDS, false>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy, anyTex,
+                                        px, py, best, bid);
+        }
+    }
+    MRX_STAMP(5);
+    MRX_STAMP(6);
+#undef MRX_STAMP
+}
+
 }  // namespace
 
 hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
@@ -790,27 +1070,40 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
     const uint32_t items = p.numViews * p.tilesFast * p.tilesSlow;
     if (items == 0)
         return hipSuccess;
-    // brute: one wave per tile; strip: one workgroup per tile
-    const dim3 grid(variant == kVariantBrute ? (items + kWavesPerBlock - 1) / kWavesPerBlock
-                                             : items);
     const dim3 block(kWave * kWavesPerBlock);
     const bool ids = p.ids != nullptr;
     const bool multi = maxWorldTris > (uint32_t)kChunk;
-#define MRX_LAUNCH(KERNEL)                                                     \
+    if (variant == kVariantBrute) {
+        // v1 reference: one wave per tile, every triangle at every pixel
+        const dim3 grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
+        if (ids) {
+            if (multi) rasterBruteKernel<true, true><<<grid, block, 0, stream>>>(p);
+            else       rasterBruteKernel<true, false><<<grid, block, 0, stream>>>(p);
+        } else {
+            if (multi) rasterBruteKernel<false, true><<<grid, block, 0, stream>>>(p);
+            else       rasterBruteKernel<false, false><<<grid, block, 0, stream>>>(p);
+        }
+    } else if (multi) {
+        // more than one chunk of triangles per world: one workgroup per tile
+        if (ids) rasterStripKernel<true, true><<<dim3(items), block, 0, stream>>>(p);
+        else     rasterStripKernel<false, true><<<dim3(items), block, 0, stream>>>(p);
+    } else {
+        // dense setup: 64 / SLOTS tiles per workgroup
+        int slots = maxWorldTris <= 16 ? 16 : maxWorldTris <= 32 ? 32 : 64;
+        if (p.debugSlots >= slots && (p.debugSlots == 32 || p.debugSlots == 64))
+            slots = p.debugSlots;                 // tuning aid (MRX_DEBUG_SLOTS)
+        const uint32_t g = (uint32_t)(kChunk / slots);
+        const dim3 grid((items + g - 1) / g);
+#define MRX_GROUP(S)                                                           \
     do {                                                                       \
-        if (ids) {                                                             \
-            if (multi) KERNEL<true, true><<<grid, block, 0, stream>>>(p);      \
-            else       KERNEL<true, false><<<grid, block, 0, stream>>>(p);     \
-        } else {                                                               \
-            if (multi) KERNEL<false, true><<<grid, block, 0, stream>>>(p);     \
-            else       KERNEL<false, false><<<grid, block, 0, stream>>>(p);    \
-        }                                                                      \
+        if (ids) rasterGroupKernel<true, S><<<grid, block, 0, stream>>>(p);    \
+        else     rasterGroupKernel<false, S><<<grid, block, 0, stream>>>(p);   \
     } while (0)
-    switch (variant) {
-    case kVariantBrute: MRX_LAUNCH(rasterBruteKernel); break;
-    default:            MRX_LAUNCH(rasterStripKernel); break;
+        if (slots == 16) MRX_GROUP(16);
+        else if (slots == 32) MRX_GROUP(32);
+        else MRX_GROUP(64);
+#undef MRX_GROUP
     }
-#undef MRX_LAUNCH
     return hipGetLastError();
 }
 

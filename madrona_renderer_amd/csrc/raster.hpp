@@ -73,6 +73,10 @@ struct RasterParams {
     // production): 1 skip stores, 2 skip raster, 4 skip classification,
     // 8 skip triangle setup.  Outputs are wrong when any bit is set.
     uint32_t debugSkip;
+    int32_t debugSlots;              // MRX_DEBUG_SLOTS: force 32 / 64 triangle slots per tile
+    // Diagnostic only (MRX_DEBUG_STAMPS=1): per-wave s_memrealtime stamps,
+    // [workgroup][wave][8], written to memory nothing else reads.
+    unsigned long long *debugStamps;
 };
 
 // Kernel variants (mrx_config.kernel_variant).

@@ -1,0 +1,30 @@
+"""In-kernel timeline (diagnostic build path: MRX_DEBUG_STAMPS=1)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MRX_DEBUG_STAMPS"] = "1"
+import numpy as np
+import madrona_renderer_amd as pkg
+from madrona_renderer_amd import scenes
+worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+r = scenes.make_renderer(scenes.synthetic_scene(worlds))
+for _ in range(5):
+    r.step()
+r.sync()
+lib = pkg.load_capi()
+lib.mrx_debug_stamps.restype = ctypes.c_int64
+lib.mrx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+buf = np.zeros(worlds * 4 * 8, np.uint64)
+n = lib.mrx_debug_stamps(ctypes.c_void_p(r.native_handle()), buf.ctypes.data, buf.size)
+st = buf[:n].reshape(-1, 4, 8).astype(np.int64)
+wgs = st[st[:, 0, 0] > 0]
+t0 = wgs[:, :, 0].min()
+us = (wgs - t0) / 100.0
+print("workgroups", len(wgs), " kernel span %.1f us" % us[:, :, 6].max())
+names = ["entry", "S loads issued", "setup done", "classify done", "after barrier", "tile0 done", "exit"]
+for i, nm in enumerate(names):
+    sel = us[:, 0, i] if i in (1, 2, 3) else us[:, :, i].reshape(-1)
+    print(f"{nm:16s} min {sel.min():6.2f}  p50 {np.median(sel):6.2f}  p90 {np.percentile(sel, 90):6.2f}  max {sel.max():6.2f}")
+life = us[:, :, 6] - us[:, :, 0]
+print("wave lifetime   p50 %.2f  max %.2f" % (np.median(life), life.max()))
+print("S phase (wave0) p50 %.2f" % np.median(us[:, 0, 3] - us[:, 0, 0]))
+print("barrier->exit   p50 %.2f" % np.median(us[:, :, 6] - us[:, :, 4]))
