@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -109,6 +112,47 @@ struct mrx_renderer {
 
 namespace {
 
+// S6b support: is the object a closed, consistently wound triangle mesh?
+// Vertices are welded by exact position; closed <=> every directed edge occurs
+// once and so does its reverse.  Returns the sign of the enclosed volume
+// (+1 outward winding, -1 inward) or 0 when the mesh is open / inconsistent.
+float closedOrientation(const mrx::ObjTri *tris, uint32_t n)
+{
+    if (n < 4)
+        return 0.0f;
+    std::map<std::array<uint32_t, 3>, uint32_t> ids;
+    std::map<std::pair<uint32_t, uint32_t>, int> edges;
+    double vol = 0.0;
+    for (uint32_t t = 0; t < n; ++t) {
+        uint32_t v[3];
+        for (int c = 0; c < 3; ++c) {
+            std::array<uint32_t, 3> key;
+            std::memcpy(key.data(), tris[t].p + 3 * c, 12);
+            for (uint32_t &w : key)
+                if (w == 0x80000000u) w = 0;            // -0 == +0
+            auto it = ids.find(key);
+            if (it == ids.end())
+                it = ids.emplace(key, (uint32_t)ids.size()).first;
+            v[c] = it->second;
+        }
+        if (v[0] == v[1] || v[1] == v[2] || v[2] == v[0])
+            return 0.0f;
+        for (int c = 0; c < 3; ++c)
+            if (++edges[{ v[c], v[(c + 1) % 3] }] > 1)
+                return 0.0f;
+        const float *a = tris[t].p, *b = a + 3, *c3 = a + 6;
+        vol += (double)a[0] * ((double)b[1] * c3[2] - (double)b[2] * c3[1]) +
+               (double)a[1] * ((double)b[2] * c3[0] - (double)b[0] * c3[2]) +
+               (double)a[2] * ((double)b[0] * c3[1] - (double)b[1] * c3[0]);
+    }
+    for (const auto &e : edges) {
+        auto rev = edges.find({ e.first.second, e.first.first });
+        if (rev == edges.end())
+            return 0.0f;
+    }
+    return vol > 0.0 ? 1.0f : vol < 0.0 ? -1.0f : 0.0f;
+}
+
 int buildScene(const mrx_config &cfg, mrx_renderer &r)
 {
     using namespace mrx;
@@ -194,6 +238,29 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         }
         if (tm.tex < 0 || (uint32_t)tm.tex >= (uint32_t)texDescs.size())
             tm.tex = -1;
+    }
+    // S6b: per-object orientation and padded bounding box, copied per triangle
+    for (size_t o = 0; o < r.objFirst.size(); ++o) {
+        const uint32_t f = (uint32_t)r.objFirst[o], n = (uint32_t)r.objCount[o];
+        const float orient = closedOrientation(tris.data() + f, n);
+        float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+        for (uint32_t t = 0; t < n; ++t)
+            for (int c = 0; c < 3; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    const float x = tris[f + t].p[3 * c + a];
+                    if ((t == 0 && c == 0) || x < lo[a]) lo[a] = x;
+                    if ((t == 0 && c == 0) || x > hi[a]) hi[a] = x;
+                }
+        for (int a = 0; a < 3; ++a) {
+            const float pad = 1e-4f * (hi[a] - lo[a]) + 1e-6f;
+            lo[a] -= pad;
+            hi[a] += pad;
+        }
+        for (uint32_t t = 0; t < n; ++t) {
+            triMats[f + t].orient = orient;
+            std::memcpy(triMats[f + t].bbMin, lo, 12);
+            std::memcpy(triMats[f + t].bbMax, hi, 12);
+        }
     }
 
     // ---- world assembly: per-world copies of the table rows, world-major

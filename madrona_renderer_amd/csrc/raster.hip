@@ -126,8 +126,25 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     __builtin_amdgcn_sched_barrier(0);
     const float4 *src = reinterpret_cast<const float4 *>(p.tris + wt.tri);
     const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
-    const float4 mc = *reinterpret_cast<const float4 *>(p.triMats[wt.tri].color);
-    const int32_t tex = p.triMats[wt.tri].tex;
+    const float4 *msrc = reinterpret_cast<const float4 *>(p.triMats + wt.tri);
+    const float4 mc = msrc[0], m1 = msrc[1], m2 = msrc[2];
+    const int32_t tex = __float_as_int(m1.x);
+    // S6b: is the eye outside the object's (padded) bounding box?  Camera into
+    // object space: c_obj = diag(1/s) Ri^T (c - t).
+    bool cullBack = false, cullFront = false;
+    {
+        const float orient = m1.y;
+        const float bmin[3] = { m1.z, m1.w, m2.x }, bmax[3] = { m2.y, m2.z, m2.w };
+        bool outside = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float co = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]) / sc[r];
+            outside = outside || co < bmin[r] || co > bmax[r];
+        }
+        const float handed = orient * ((s0 * s1) * s2);   // mirroring flips the winding
+        cullBack = outside && handed > 0.0f;
+        cullFront = outside && handed < 0.0f;
+    }
     const float op[9] = { t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x };
     const float uv[6] = { t2.y, t2.z, t2.w, t3.x, t3.y, t3.z };
 
@@ -151,7 +168,9 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     }
     cross3(e1, e2, nn);
     const float d = dot3(nn[0], nn[1], nn[2], P[0][0], P[0][1], P[0][2]);
-    const bool valid = fabsf(d) > 0.0f;                       // S6
+    // S6: degenerate / edge-on triangles; S6b: faces of a closed object turned
+    // away from an eye outside the object can never be the nearest hit
+    const bool valid = fabsf(d) > 0.0f && !(cullBack && d > 0.0f) && !(cullFront && d < 0.0f);
     __builtin_amdgcn_sched_barrier(0);
 
     // Binning aid: pixel-space bounding box of the projected vertices, padded

@@ -19,10 +19,16 @@ static_assert(sizeof(ObjTri) == 64, "ObjTri must be one 64-byte line");
 // default colour; texture index validated): one 32-byte record next to ObjTri.
 struct alignas(16) TriMat {
     float color[4];
-    int32_t tex;     // texture index, -1 = untextured
-    int32_t pad[3];
+    int32_t tex;       // texture index, -1 = untextured
+    // S6b back-face culling data of the triangle's object: orient = +1 / -1
+    // when the object is a closed, consistently wound mesh (sign of its
+    // volume), 0 otherwise; bb = its object-space bounding box, padded
+    float orient;
+    float bbMin[3];
+    float bbMax[3];
+    int32_t pad[4];
 };
-static_assert(sizeof(TriMat) == 32, "TriMat layout");
+static_assert(sizeof(TriMat) == 64, "TriMat layout");
 
 struct TexDesc {
     uint32_t offset;  // texel offset into the RGBA8 pool

@@ -46,6 +46,8 @@ class _Scene(ctypes.Structure):
         ("tri_pos", ctypes.c_void_p), ("tri_uv", ctypes.c_void_p),
         ("tri_mat", ctypes.c_void_p), ("obj_first_tri", ctypes.c_void_p),
         ("obj_num_tris", ctypes.c_void_p), ("num_objects", ctypes.c_int32),
+        ("obj_orient", ctypes.c_void_p), ("obj_bbmin", ctypes.c_void_p),
+        ("obj_bbmax", ctypes.c_void_p),
         ("mat_color", ctypes.c_void_p), ("mat_tex", ctypes.c_void_p),
         ("num_materials", ctypes.c_int32),
         ("tex_data", ctypes.c_void_p), ("tex_offset", ctypes.c_void_p),
@@ -129,6 +131,46 @@ def parse_obj(path):
     pos = np.asarray(tris_p, dtype=np.float64).astype(np.float32).reshape(-1, 3, 3)
     uv = np.asarray(tris_t, dtype=np.float64).astype(np.float32).reshape(-1, 3, 2)
     return pos, uv
+
+
+def closed_orientation(tri_pos):
+    """S6b: +1 / -1 (sign of the enclosed volume) when the triangle soup is a
+    closed, consistently wound mesh -- every directed edge occurs exactly once
+    and so does its reverse, vertices welded by exact position -- else 0."""
+    n = len(tri_pos)
+    if n < 4:
+        return 0.0
+    ids, edges = {}, {}
+    vol = 0.0
+    for t in range(n):
+        v = []
+        for c in range(3):
+            key = tuple(float(x) + 0.0 for x in tri_pos[t, c])     # -0 -> +0
+            v.append(ids.setdefault(key, len(ids)))
+        if len(set(v)) < 3:
+            return 0.0
+        for c in range(3):
+            e = (v[c], v[(c + 1) % 3])
+            if e in edges:
+                return 0.0
+            edges[e] = 1
+        a, b, c3 = (tri_pos[t, i].astype(np.float64) for i in range(3))
+        vol += float(a @ np.cross(b, c3))
+    for (i, j) in edges:
+        if (j, i) not in edges:
+            return 0.0
+    return 1.0 if vol > 0 else -1.0 if vol < 0 else 0.0
+
+
+def padded_bounds(tri_pos):
+    """Object-space bounding box padded by 1e-4 of its extent + 1e-6 (float32)."""
+    if len(tri_pos) == 0:
+        z = np.zeros(3, np.float32)
+        return z, z
+    pts = tri_pos.reshape(-1, 3).astype(np.float32)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    pad = np.float32(1e-4) * (hi - lo) + np.float32(1e-6)
+    return (lo - pad).astype(np.float32), (hi + pad).astype(np.float32)
 
 
 def decode_image(path):
@@ -219,6 +261,15 @@ class FlatScene:
             np.concatenate(mat_l) if mat_l else np.zeros(0), np.int32)
         self.obj_first_tri = np.asarray(first, dtype=np.int32)
         self.obj_num_tris = np.asarray(count, dtype=np.int32)
+        orient, bmin, bmax = [], [], []
+        for f, c in zip(first, count):
+            orient.append(closed_orientation(self.tri_pos[f:f + c]))
+            lo, hi = padded_bounds(self.tri_pos[f:f + c])
+            bmin.append(lo)
+            bmax.append(hi)
+        self.obj_orient = np.asarray(orient, dtype=np.float32)
+        self.obj_bbmin = np.asarray(bmin, dtype=np.float32).reshape(-1, 3)
+        self.obj_bbmax = np.asarray(bmax, dtype=np.float32).reshape(-1, 3)
 
         # -- materials / textures
         mats = list(desc.materials)
@@ -275,6 +326,8 @@ class FlatScene:
         s.obj_first_tri = ptr(self.obj_first_tri)
         s.obj_num_tris = ptr(self.obj_num_tris)
         s.num_objects = len(self.obj_first_tri)
+        s.obj_orient = ptr(self.obj_orient)
+        s.obj_bbmin = ptr(self.obj_bbmin); s.obj_bbmax = ptr(self.obj_bbmax)
         s.mat_color = ptr(self.mat_color); s.mat_tex = ptr(self.mat_tex)
         s.num_materials = len(self.mat_tex)
         s.tex_data = ptr(self.tex_data); s.tex_offset = ptr(self.tex_offset)

@@ -47,6 +47,11 @@ typedef struct {
     const int32_t *obj_first_tri;  /* [O]                                     */
     const int32_t *obj_num_tris;   /* [O]                                     */
     int32_t        num_objects;
+    /* S6b: +1 / -1 for closed, consistently wound meshes (volume sign), else 0;
+     * padded object-space bounding box */
+    const float   *obj_orient;     /* [O]                                     */
+    const float   *obj_bbmin;      /* [O][3]                                  */
+    const float   *obj_bbmax;      /* [O][3]                                  */
     /* materials / textures */
     const float   *mat_color;      /* [M][rgba]                               */
     const int32_t *mat_tex;        /* [M] texture index, -1 = none            */
@@ -153,6 +158,19 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
         for (int r = 0; r < 3; ++r)
             tv[r] = dot3(Rc[0][r], Rc[1][r], Rc[2][r], dt[0], dt[1], dt[2]);
 
+        /* S6b: eye in object space, c_obj = diag(1/s) Ri^T (c - t) */
+        int cull_back = 0, cull_front = 0;
+        {
+            int outside = 0;
+            for (int r = 0; r < 3; ++r) {
+                const float co = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]) / sc[r];
+                if (co < s->obj_bbmin[3 * obj + r] || co > s->obj_bbmax[3 * obj + r])
+                    outside = 1;
+            }
+            const float handed = s->obj_orient[obj] * ((sc[0] * sc[1]) * sc[2]);
+            cull_back = outside && handed > 0.0f;
+            cull_front = outside && handed < 0.0f;
+        }
         const int first = s->obj_first_tri[obj];
         const int cnt = s->obj_num_tris[obj];
         for (int ti = first; ti < first + cnt; ++ti, ++k) {
@@ -175,6 +193,8 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
             const float d = dot3(nn[0], nn[1], nn[2], P[0][0], P[0][1], P[0][2]);
             if (!(fabsf(d) > 0.0f))
                 continue;                                   /* S6: cull */
+            if ((cull_back && d > 0.0f) || (cull_front && d < 0.0f))
+                continue;                                   /* S6b */
             orc_tri *o = &out[n++];
             const float flip = d < 0.0f ? -1.0f : 1.0f;
             for (int e = 0; e < 3; ++e) {
