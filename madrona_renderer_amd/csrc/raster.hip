@@ -523,10 +523,14 @@ __device__ __forceinline__ bool setupLane(const RasterParams &p, const ViewConst
 // so the per-pixel near test can be dropped for this triangle.
 constexpr uint32_t kNearFree = 1u << 16;
 
-__device__ __forceinline__ uint32_t classifyRegions(const TriPlanes &c, const TileCtx &t,
-                                                    float invNear, float invFar)
+// Region bits of strips [S0, S1) for the lane's triangle; `nearOk` reports
+// whether the 1/depth plane stays <= invNear over those strips.
+template <int S0, int S1>
+__device__ __forceinline__ uint32_t classifyStrips(const TriPlanes &c, uint32_t tileX0,
+                                                   uint32_t tileY0, float invNear, float invFar,
+                                                   bool &nearOk)
 {
-    const float X0 = (float)t.tileX0, Y0 = (float)t.tileY0;
+    const float X0 = (float)tileX0, Y0 = (float)tileY0;
     // x / y of the region pixel where each plane is largest (depth: also smallest)
     const float xa0 = c.A0 < 0.0f ? X0 : X0 + 31.0f;
     const float xa1 = c.A1 < 0.0f ? X0 : X0 + 31.0f;
@@ -541,7 +545,7 @@ __device__ __forceinline__ uint32_t classifyRegions(const TriPlanes &c, const Ti
     uint32_t mask = 0;
     float dmax = -__builtin_inff();
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = S0; s < S1; ++s) {
         const float dy = (float)(8 * s);
         const float r0 = __builtin_fmaf(c.B0, yb0 + dy, c.C0);
         const float r1 = __builtin_fmaf(c.B1, yb1 + dy, c.C1);
@@ -564,10 +568,21 @@ __device__ __forceinline__ uint32_t classifyRegions(const TriPlanes &c, const Ti
             dmax = fmaxf(dmax, dh);
         }
     }
-    if (dmax <= invNear)
+    nearOk = dmax <= invNear;
+    return mask;
+}
+
+__device__ __forceinline__ uint32_t classifyRegions(const TriPlanes &c, const TileCtx &t,
+                                                    float invNear, float invFar)
+{
+    bool nearOk;
+    uint32_t mask = classifyStrips<0, 8>(c, t.tileX0, t.tileY0, invNear, invFar, nearOk);
+    if (nearOk)
         mask |= kNearFree;
     return mask;
 }
+
+#define MRX_READLANE_F(v, k) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (k)))
 
 constexpr int kRegionBlocks = 4;    // a region is 32 x 8 pixels = 4 blocks of 8x8
 
@@ -815,7 +830,8 @@ void rasterStripKernel(const RasterParams p)
 constexpr int kBackground = kChunk;   // record index of "nothing hit"
 
 struct GroupLds {
-    float planes[kChunk][16];           // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | mask
+    float planes[kChunk][16];           // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | bbox
+    uint32_t masks[kChunk];             // region bits 0..15, near-free bits 16..19, live bit 31
     float shade[kChunk + 1][4];         // rgba, texture, objectID, world-local index
     float cold[kChunk][kCold];          // u/v planes, lit colour
     uint32_t tileInfo[4][4];            // per tile of the group: view, x0, y0, flags
@@ -912,7 +928,9 @@ void rasterGroupKernel(const RasterParams p)
 {
     constexpr int G = kChunk / SLOTS;
     __shared__ GroupLds lds;
-    const int wave = threadIdx.x / kWave;
+    // readfirstlane: the compiler cannot see that threadIdx.x / 64 is
+    // wave-uniform and would predicate every `wave` branch instead of jumping
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
     const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
     const uint32_t numItems = p.numViews * tilesPerView;
@@ -927,7 +945,7 @@ void rasterGroupKernel(const RasterParams p)
     } while (0)
     MRX_STAMP(0);
 
-    // ---- S: wave 0, lane = (tile j of the group, triangle slot k)
+    // ---- S1: wave 0, lane = (tile j of the group, triangle slot k): setup
     if (wave == 0) {
         const int j = lane / SLOTS, k = lane % SLOTS;
         const uint32_t item = item0 + j;
@@ -938,8 +956,11 @@ void rasterGroupKernel(const RasterParams p)
         t.tileX0 = (tile % p.tilesFast) * 64u;
         t.tileY0 = (tile / p.tilesFast) * 64u;
         t.triBegin = t.view * p.viewTriStride;
-        t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
         t.lx = t.ly = 0;
+        // everything addressed by the view index is requested up front; the
+        // pose / geometry rows one level down follow as soon as wt arrives
+        const WorldTri wt = p.viewTris[t.triBegin + k];
+        t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
         ViewConst vc;
         {
             const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * t.view);
@@ -958,32 +979,21 @@ void rasterGroupKernel(const RasterParams p)
         bool valid = false;
         lds.shade[lane][1] = __int_as_float(-1);
         MRX_STAMP(1);
-        if ((uint32_t)k < t.numTris && !(p.debugSkip & 8u)) {
-            const WorldTri wt = p.viewTris[t.triBegin + k];
+        if ((uint32_t)k < t.numTris && !(p.debugSkip & 8u))
             valid = setupTriangle(p, vc, wt, k, c, lds.shade[lane], lds.cold[lane]);
-        }
         MRX_STAMP(2);
-        uint32_t mask = 0;
-        if (valid && !(p.debugSkip & 4u))
-            mask = classifyRegions(c, t, invNear, invFar);
-        MRX_STAMP(3);
         float4 *dst = reinterpret_cast<float4 *>(lds.planes[lane]);
         dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
         dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
         dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
-        dst[3] = make_float4(__uint_as_float(mask), 0.f, 0.f, 0.f);
-        // per-tile flags from sub-ballots of the tile's SLOTS lanes
-        const uint64_t slotBits = SLOTS == 64 ? ~0ull : ((1ull << SLOTS) - 1ull);
-        const uint64_t texB = __ballot(mask != 0 && __float_as_int(lds.shade[lane][1]) >= 0);
-        const uint64_t nearB = __ballot(mask != 0 && !(mask & kNearFree));
+        dst[3] = make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1);
+        // bit 31 marks a live triangle until classification replaces the word
+        lds.masks[lane] = (valid && !(p.debugSkip & 4u)) ? 0x80000000u : 0u;
         if (k == 0) {
-            uint32_t fl = tileOk ? kTileValid : 0u;
-            if ((texB >> (j * SLOTS)) & slotBits) fl |= kTileAnyTex;
-            if (((nearB >> (j * SLOTS)) & slotBits) == 0) fl |= kTileNearFree;
             lds.tileInfo[j][0] = t.view;
             lds.tileInfo[j][1] = t.tileX0;
             lds.tileInfo[j][2] = t.tileY0;
-            lds.tileInfo[j][3] = fl;
+            lds.tileInfo[j][3] = tileOk ? kTileValid : 0u;
         }
         if (lane == 0) {
             lds.nextItem = 0;
@@ -994,11 +1004,44 @@ void rasterGroupKernel(const RasterParams p)
         }
     }
     __syncthreads();
+    MRX_STAMP(3);
+
+    // ---- S2: every wave classifies two strips (four 32x8 regions) of each triangle
+    //      (lane = the same (tile, slot) as in S1), results OR-ed in LDS:
+    //      bits 0..15 regions, bits 16..19 "near-free over this wave's strips"
+    {
+        const int j = lane / SLOTS;
+        const float4 *src = reinterpret_cast<const float4 *>(lds.planes[lane]);
+        const float4 a = src[0], b = src[1], cc = src[2], bb = src[3];
+        TriPlanes c;
+        c.A0 = a.x; c.A1 = a.y; c.A2 = a.z; c.Dx = a.w;
+        c.B0 = b.x; c.B1 = b.y; c.B2 = b.z; c.Dy = b.w;
+        c.C0 = cc.x; c.C1 = cc.y; c.C2 = cc.z; c.Dc = cc.w;
+        c.bbX0 = bb.x; c.bbX1 = bb.y; c.bbY0 = bb.z; c.bbY1 = bb.w;
+        const uint32_t tx0 = lds.tileInfo[j][1], ty0 = lds.tileInfo[j][2];
+        if (lds.masks[lane] & 0x80000000u) {
+            bool nearOk = false;
+            uint32_t m;
+            switch (wave) {
+            case 0: m = classifyStrips<0, 2>(c, tx0, ty0, invNear, invFar, nearOk); break;
+            case 1: m = classifyStrips<2, 4>(c, tx0, ty0, invNear, invFar, nearOk); break;
+            case 2: m = classifyStrips<4, 6>(c, tx0, ty0, invNear, invFar, nearOk); break;
+            default: m = classifyStrips<6, 8>(c, tx0, ty0, invNear, invFar, nearOk); break;
+            }
+            if (nearOk)
+                m |= 1u << (16 + wave);
+            if (m)
+                atomicOr(&lds.masks[lane], m);
+        }
+    }
+    __syncthreads();
     MRX_STAMP(4);
 
     // ---- R + O: the four waves pull (tile, strip) work items off an LDS
     //      counter -- strips differ a lot in cost (sky vs. ground vs. objects),
     //      a static split leaves waves idle
+    // lane -> four consecutive pixels of one row of a 32x8 region (a 64x4
+    // region with fully linear 1 KiB stores was measured slower: no x culling)
     const int lx = lane & 7, ly = lane >> 3;
     const uint32_t laneOff = (uint32_t)ly * p.nfast + 4u * lx;
     int cachedTile = -1;
@@ -1024,15 +1067,18 @@ void rasterGroupKernel(const RasterParams p)
             view = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][0]);
             tileX0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][1]);
             tileY0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][2]);
-            anyTex = flags & kTileAnyTex;
-            nearFree = flags & kTileNearFree;
             const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
             rgbTile = p.rgb + tileBase;
             depthTile = p.depth + tileBase;
             idsTile = IDS ? p.ids + tileBase : nullptr;
             full = (p.nfast & 3u) == 0 && tileX0 + 64u <= p.nfast && tileY0 + 64u <= p.nslow;
             // lane k < SLOTS looks at the region mask of triangle slot k of tile j
-            mask = lane < SLOTS ? __float_as_uint(lds.planes[j * SLOTS + lane][12]) : 0u;
+            mask = lane < SLOTS ? lds.masks[j * SLOTS + lane] : 0u;
+            const int32_t tex = lane < SLOTS ? __float_as_int(lds.shade[j * SLOTS + lane][1]) : -1;
+            anyTex = __ballot((mask & 0xFFFFu) != 0 && tex >= 0) != 0;
+            // every surviving triangle stays behind the near plane over the
+            // whole tile: the per-pixel near test is dropped for the tile
+            nearFree = __ballot((mask & 0xFFFFu) != 0 && ((mask >> 16) & 0xFu) != 0xFu) == 0;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
