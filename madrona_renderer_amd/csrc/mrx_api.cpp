@@ -348,6 +348,37 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.viewTris = r.viewTris.ptr;
     p.viewTriCount = r.viewTriCount.ptr;
     p.viewTriStride = stride;
+    // uniform worlds -> arithmetic draw list (raster.hpp)
+    p.uniInstances = 0;
+    p.uniCamsPerWorld = 0;
+    if (cfg.num_worlds > 0) {
+        const mrx_world_init &w0 = cfg.worlds[0];
+        bool uni = w0.num_instances >= 1 && w0.num_instances <= 4 && w0.num_cameras >= 1;
+        for (uint32_t w = 0; uni && w < cfg.num_worlds; ++w) {
+            const mrx_world_init &wi = cfg.worlds[w];
+            uni = wi.num_instances == w0.num_instances && wi.num_cameras == w0.num_cameras;
+            for (uint32_t i = 0; uni && i < wi.num_instances; ++i) {
+                const int32_t oa = cfg.instances[wi.instances_offset + i].object_id;
+                const int32_t ob = cfg.instances[w0.instances_offset + i].object_id;
+                uni = oa == ob && oa >= 0 && (size_t)oa < r.objFirst.size();
+            }
+        }
+        if (uni) {
+            p.uniInstances = w0.num_instances;
+            p.uniCamsPerWorld = w0.num_cameras;
+            uint32_t acc = 0;
+            for (uint32_t i = 0; i < 4; ++i) {
+                p.uniPrefix[i] = acc;
+                p.uniFirstTri[i] = 0;
+                if (i < w0.num_instances) {
+                    const int32_t o = cfg.instances[w0.instances_offset + i].object_id;
+                    p.uniFirstTri[i] = (uint32_t)r.objFirst[o];
+                    acc += (uint32_t)r.objCount[o];
+                }
+            }
+            p.uniPrefix[4] = acc;
+        }
+    }
     p.instPos = r.instPos.ptr;
     p.instRot = r.instRot.ptr;
     p.instScale = r.instScale.ptr;

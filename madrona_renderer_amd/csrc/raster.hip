@@ -129,8 +129,9 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     const float4 *msrc = reinterpret_cast<const float4 *>(p.triMats + wt.tri);
     const float4 mc = msrc[0], m1 = msrc[1], m2 = msrc[2];
     const int32_t tex = __float_as_int(m1.x);
-    // S6b: is the eye outside the object's (padded) bounding box?  Camera into
-    // object space: c_obj = diag(1/s) Ri^T (c - t).
+    // S6b: is the eye outside the object's (padded) bounding box?  The eye in
+    // the instance's unscaled frame, q = Ri^T (c - t), against the box scaled
+    // by s (no division).
     bool cullBack = false, cullFront = false;
     {
         const float orient = m1.y;
@@ -138,8 +139,9 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
         bool outside = false;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float co = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]) / sc[r];
-            outside = outside || co < bmin[r] || co > bmax[r];
+            const float qo = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]);
+            const float b0 = bmin[r] * sc[r], b1 = bmax[r] * sc[r];
+            outside = outside || qo < fminf(b0, b1) || qo > fmaxf(b0, b1);
         }
         const float handed = orient * ((s0 * s1) * s2);   // mirroring flips the winding
         cullBack = outside && handed > 0.0f;
@@ -958,9 +960,28 @@ void rasterGroupKernel(const RasterParams p)
         t.triBegin = t.view * p.viewTriStride;
         t.lx = t.ly = 0;
         // everything addressed by the view index is requested up front; the
-        // pose / geometry rows one level down follow as soon as wt arrives
-        const WorldTri wt = p.viewTris[t.triBegin + k];
-        t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
+        // pose / geometry rows one level down follow as soon as wt arrives --
+        // or at once, when the draw list is arithmetic (uniform worlds)
+        WorldTri wt;
+        if (p.uniInstances) {
+            const uint32_t kk = (uint32_t)k;
+            const uint32_t li = (kk >= p.uniPrefix[1] ? 1u : 0u) + (kk >= p.uniPrefix[2] ? 1u : 0u) +
+                                (kk >= p.uniPrefix[3] ? 1u : 0u);
+            const uint32_t pre = li == 0 ? p.uniPrefix[0] : li == 1 ? p.uniPrefix[1]
+                               : li == 2 ? p.uniPrefix[2] : p.uniPrefix[3];
+            const uint32_t first = li == 0 ? p.uniFirstTri[0] : li == 1 ? p.uniFirstTri[1]
+                                 : li == 2 ? p.uniFirstTri[2] : p.uniFirstTri[3];
+            wt.inst = (t.view / p.uniCamsPerWorld) * p.uniInstances + li;
+            wt.tri = first + (kk - pre);
+            t.numTris = tileOk ? p.uniPrefix[4] : 0u;
+            if (kk >= p.uniPrefix[4]) {           // idle slot: keep the loads in range
+                wt.inst = 0;
+                wt.tri = 0;
+            }
+        } else {
+            wt = p.viewTris[t.triBegin + k];
+            t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
+        }
         ViewConst vc;
         {
             const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * t.view);

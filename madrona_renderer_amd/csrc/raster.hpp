@@ -54,6 +54,15 @@ struct RasterParams {
     const WorldTri *viewTris;
     const uint32_t *viewTriCount;    // [views]
     uint32_t viewTriStride;
+    // Uniform worlds (every world: the same <= 4 objects in the same order, the
+    // same camera count): the draw list is arithmetic on kernel arguments --
+    // slot k of a view belongs to local instance i with uniPrefix[i] <= k <
+    // uniPrefix[i+1], object triangle uniFirstTri[i] + k - uniPrefix[i] -- so
+    // no table load sits between the view index and the pose / geometry rows.
+    uint32_t uniInstances;           // instances per world, 0 = not uniform
+    uint32_t uniCamsPerWorld;
+    uint32_t uniPrefix[5];
+    uint32_t uniFirstTri[4];
     // pose state (the exported, mutable tensors)
     const float *instPos;            // [I][3]
     const float *instRot;            // [I][4] w,x,y,z

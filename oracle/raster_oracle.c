@@ -158,13 +158,16 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
         for (int r = 0; r < 3; ++r)
             tv[r] = dot3(Rc[0][r], Rc[1][r], Rc[2][r], dt[0], dt[1], dt[2]);
 
-        /* S6b: eye in object space, c_obj = diag(1/s) Ri^T (c - t) */
+        /* S6b: eye in the instance's unscaled frame, q = Ri^T (c - t), against
+         * the object's padded bounding box scaled by s */
         int cull_back = 0, cull_front = 0;
         {
             int outside = 0;
             for (int r = 0; r < 3; ++r) {
-                const float co = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]) / sc[r];
-                if (co < s->obj_bbmin[3 * obj + r] || co > s->obj_bbmax[3 * obj + r])
+                const float qo = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]);
+                const float b0 = s->obj_bbmin[3 * obj + r] * sc[r];
+                const float b1 = s->obj_bbmax[3 * obj + r] * sc[r];
+                if (qo < fminf(b0, b1) || qo > fmaxf(b0, b1))
                     outside = 1;
             }
             const float handed = s->obj_orient[obj] * ((sc[0] * sc[1]) * sc[2]);

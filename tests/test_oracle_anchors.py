@@ -201,3 +201,35 @@ def test_two_sided_coverage_and_light_direction(oracle_mod):
     cc = c["tri_id"][0] >= 0
     lit = 0.25 + 0.75 * (1.0 / math.sqrt(2.0 + 0.05 ** 2))
     assert abs(int(c["rgb"][0][cc][0, 0]) - int(lit * 255 + 0.5)) <= 1
+
+
+# ---- S6b: back faces of closed meshes are culled only where that cannot
+#      change the image (eye outside the object's bounding box)
+def test_closed_mesh_detection(oracle_mod):
+    cube, _ = oracle_mod.parse_obj(CUBE)
+    plane, _ = oracle_mod.parse_obj(PLANE)
+    assert oracle_mod.closed_orientation(cube) == 1.0
+    assert oracle_mod.closed_orientation(plane) == 0.0            # open
+    assert oracle_mod.closed_orientation(cube[:, ::-1]) == -1.0   # inward winding
+    assert oracle_mod.closed_orientation(cube[:-1]) == 0.0        # a hole
+    mixed = cube.copy()
+    mixed[0] = mixed[0, ::-1]                                     # one flipped face
+    assert oracle_mod.closed_orientation(mixed) == 0.0
+
+
+def test_back_faces_culled_outside_but_not_inside(oracle_mod):
+    ident = (1.0, 0.0, 0.0, 0.0)
+    box = [((0.0, 6.0, 0.0), ident, (2.0, 2.0, 2.0), 0)]
+    outside = render_oracle(_one_world(box, [(CUBE, -1)], cam=((0.0, 0.0, 0.0), ident)))
+    ids = outside["tri_id"][0]
+    # seen face-on from -Y only the two triangles of the y = -0.5 face survive
+    assert set(np.unique(ids[ids >= 0])) == {0, 1}
+    np.testing.assert_allclose(outside["depth"][0][ids >= 0], 5.0, rtol=1e-6)
+    # eye inside the cube: every pixel sees an inner wall (those are back faces)
+    inside = render_oracle(_one_world(box, [(CUBE, -1)], cam=((0.0, 6.0, 0.0), ident)))
+    assert (inside["tri_id"][0] >= 0).all()
+    # a mirrored instance (negative scale) flips the winding, not the image
+    mirrored = [((0.0, 6.0, 0.0), ident, (-2.0, 2.0, 2.0), 0)]
+    m = render_oracle(_one_world(mirrored, [(CUBE, -1)], cam=((0.0, 0.0, 0.0), ident)))
+    assert np.array_equal(m["tri_id"][0] >= 0, ids >= 0)
+    np.testing.assert_allclose(m["depth"][0], outside["depth"][0], rtol=1e-6)

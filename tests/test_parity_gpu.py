@@ -179,6 +179,30 @@ def test_edge_cases_empty_worlds_bad_ids_degenerate_triangles(native):
     assert (got["tri_id"][0] >= 0).any()
 
 
+def test_back_face_culling_cases(native):
+    # S6b: eye outside / inside a closed mesh, mirrored instance, open mesh
+    # with the same winding, inward-wound closed mesh given as raw geometry
+    from oracle import oracle
+    cube, cuv = oracle.parse_obj(CUBE)
+    inward = np.ascontiguousarray(cube[:, ::-1]).reshape(-1, 3)
+    d = scenes.SceneDesc(
+        num_worlds=5, width=64, height=64, asset_paths=[(CUBE, -1), (PLANE, -1)],
+        mesh_vertices=inward, mesh_uvs=np.zeros((len(inward), 2), np.float32),
+        mesh_indices=np.arange(len(inward), dtype=np.uint32),
+        mesh_vertex_offsets=np.array([0], np.uint32), mesh_indices_offsets=np.array([0], np.uint32),
+        mesh_materials=np.array([-1], np.int32),
+        instances=[((0.0, 6.0, 0.0), IDENT, (2.0, 2.0, 2.0), 0),
+                   ((0.5, 6.0, 0.3), (0.9238795, 0.0, 0.3826834, 0.0), (-2.0, 1.5, 2.5), 0),
+                   ((0.0, 6.0, -1.0), IDENT, (0.001, 0.001, 1.0), 1),
+                   ((0.0, 6.0, 0.0), IDENT, (2.0, 2.0, 2.0), 2)],
+        cameras=[((0.0, 0.0, 0.0), IDENT), ((0.0, 6.0, 0.0), IDENT),
+                 ((0.3, 5.2, 0.1), (0.9659258, 0.0, 0.0, 0.2588190))],
+        worlds=[(1, 0, 1, 0), (1, 0, 2, 1), (1, 1, 1, 0), (2, 2, 1, 0), (1, 3, 3, 0)])
+    _, got, ref = _parity(d)
+    assert got["rgb"].shape[0] == 8
+    assert (got["tri_id"][1] >= 0).all()        # eye inside the cube: walls everywhere
+
+
 def test_error_behaviour(native):
     m = native.load_module()
     r = make_product(scenes.demo_scene(num_worlds=1, render_mode="Rasterizer"), visibility=False)
