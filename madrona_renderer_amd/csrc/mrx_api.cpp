@@ -343,6 +343,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     RasterParams &p = r.params;
     p.tris = r.tris.ptr;
     p.triMats = r.triMats.ptr;
+    p.anyTextured = 0;
+    for (const mrx::WorldTri &wt : worldTris)
+        if (triMats[wt.tri].tex >= 0) {
+            p.anyTextured = 1;
+            break;
+        }
     p.textures = r.textures.ptr;
     p.texels = r.texels.ptr;
     p.viewTris = r.viewTris.ptr;

@@ -846,7 +846,7 @@ __device__ __forceinline__ const float *shadeRec(const GroupLds &L, int32_t w) {
 // Shade + store one region of a tile (group kernel).  `bid` is the byte offset
 // of the winner's shading record (the background has its own record, so the
 // lookup is unconditional); base pointers are wave-uniform.
-template <bool IDS, bool FULL>
+template <bool IDS, bool FULL, bool TEX>
 __device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLds &L,
                                             uint32_t *rgbTile, float *depthTile, int32_t *idsTile,
                                             uint32_t pixOff, uint32_t fx0, uint32_t fy,
@@ -868,7 +868,10 @@ __device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLd
         // correctly rounded quotient because texel choice depends on it
         dep[b] = bid[b] != kBackground * 16 ? __builtin_amdgcn_rcpf(best[b]) : 0.0f;
     }
-    if (anyTex) {
+    // TEX is a kernel-level switch: texel loads inside the work loop make the
+    // compiler drain vmcnt at every loop header, which would also wait for the
+    // previous strip's stores
+    if (TEX && anyTex) {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             const int32_t rec = bid[b] >> 4;
@@ -924,8 +927,13 @@ __device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t 
     }
 }
 
-template <bool IDS, int SLOTS>
-__global__ __launch_bounds__(kWave *kWavesPerBlock, 4)
+// Waves per workgroup of the group kernel: eight for untextured scenes (more
+// waves in flight absorb the stalls of a saturated store path), four for the
+// textured variant (its texel loads cost registers and vmcnt drains).
+constexpr int groupWaves(bool tex) { return tex ? 4 : 8; }
+
+template <bool IDS, int SLOTS, bool TEX>
+__global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? 4 : 8)
 void rasterGroupKernel(const RasterParams p)
 {
     constexpr int G = kChunk / SLOTS;
@@ -938,8 +946,8 @@ void rasterGroupKernel(const RasterParams p)
     const uint32_t numItems = p.numViews * tilesPerView;
     const uint32_t item0 = blockIdx.x * G;
     const float invNear = p.invNear, invFar = p.invFar;
-    unsigned long long *stamps = p.debugStamps
-        ? p.debugStamps + ((size_t)blockIdx.x * kWavesPerBlock + wave) * 8 : nullptr;
+    unsigned long long *stamps = (p.debugStamps && wave < 4)
+        ? p.debugStamps + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
 #define MRX_STAMP(i)                                                           \
     do {                                                                       \
         if (stamps && lane == 0)                                               \
@@ -1040,7 +1048,7 @@ void rasterGroupKernel(const RasterParams p)
         c.C0 = cc.x; c.C1 = cc.y; c.C2 = cc.z; c.Dc = cc.w;
         c.bbX0 = bb.x; c.bbX1 = bb.y; c.bbY0 = bb.z; c.bbY1 = bb.w;
         const uint32_t tx0 = lds.tileInfo[j][1], ty0 = lds.tileInfo[j][2];
-        if (lds.masks[lane] & 0x80000000u) {
+        if (wave < 4 && (lds.masks[lane] & 0x80000000u)) {
             bool nearOk = false;
             uint32_t m;
             switch (wave) {
@@ -1136,11 +1144,11 @@ void rasterGroupKernel(const RasterParams p)
                     rasterRegion<true, 4>(lds.planes, act, px, py, invNear, best, bid);
             }
             if (full)
-                storeRegion<IDS, true>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy, anyTex,
-                                       px, py, best, bid);
+                storeRegion<IDS, true, TEX>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy,
+                                            anyTex, px, py, best, bid);
             else
-                storeRegion<IDS, false>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy, anyTex,
-                                        px, py, best, bid);
+                storeRegion<IDS, false, TEX>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy,
+                                             anyTex, px, py, best, bid);
         }
     }
     MRX_STAMP(5);
@@ -1176,14 +1184,24 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
     } else {
         // dense setup: 64 / SLOTS tiles per workgroup
         int slots = maxWorldTris <= 16 ? 16 : maxWorldTris <= 32 ? 32 : 64;
+        // small batches: fewer tiles per workgroup so that every CU still gets
+        // about four workgroups (the group's tiles are walked one after another)
+        while (slots < 64 && (uint64_t)items * (uint32_t)slots < 64ull * 1024ull)
+            slots *= 2;
         if (p.debugSlots >= slots && (p.debugSlots == 32 || p.debugSlots == 64))
             slots = p.debugSlots;                 // tuning aid (MRX_DEBUG_SLOTS)
         const uint32_t g = (uint32_t)(kChunk / slots);
         const dim3 grid((items + g - 1) / g);
+        const dim3 gblock(kWave * groupWaves(p.anyTextured != 0));
 #define MRX_GROUP(S)                                                           \
     do {                                                                       \
-        if (ids) rasterGroupKernel<true, S><<<grid, block, 0, stream>>>(p);    \
-        else     rasterGroupKernel<false, S><<<grid, block, 0, stream>>>(p);   \
+        if (p.anyTextured) {                                                   \
+            if (ids) rasterGroupKernel<true, S, true><<<grid, gblock, 0, stream>>>(p);   \
+            else     rasterGroupKernel<false, S, true><<<grid, gblock, 0, stream>>>(p);  \
+        } else {                                                               \
+            if (ids) rasterGroupKernel<true, S, false><<<grid, gblock, 0, stream>>>(p);  \
+            else     rasterGroupKernel<false, S, false><<<grid, gblock, 0, stream>>>(p); \
+        }                                                                      \
     } while (0)
         if (slots == 16) MRX_GROUP(16);
         else if (slots == 32) MRX_GROUP(32);

@@ -48,6 +48,7 @@ struct RasterParams {
     const TriMat *triMats;           // parallel to tris
     const TexDesc *textures;
     const uint32_t *texels;          // RGBA8
+    int32_t anyTextured;             // some drawn triangle has a texture
     // per-view draw lists: view v draws viewTris[v * viewTriStride + k],
     // k < viewTriCount[v] -- one load level between the view index and the
     // triangle's pose / geometry rows
