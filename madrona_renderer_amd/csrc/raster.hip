@@ -1,19 +1,21 @@
 // Tiled software rasterizer / primary-ray caster for gfx950 (MI355X).
 //
-// One wavefront renders one 64x64 tile of one view, start to finish:
-//   S  setup     lane = triangle: pose -> view-space vertices -> edge / depth /
-//                attribute planes and the flat-shaded colour, into LDS
-//   R  raster    lane = pixel of an 8x8 block; the wave walks the 16 blocks of
-//                a 64x16 band per triangle (triangle coefficients broadcast
-//                from LDS), z / winner kept in VGPRs
-//   O  output    shade the winner, 1/depth -> depth, store
-// There is no inter-wave communication, so no workgroup barrier anywhere; a
-// workgroup is just four independent waves sharing an LDS allocation.
+// Three kernels share the spec arithmetic below:
+//   rasterGroupKernel    the production path for worlds of <= 64 triangles:
+//                        one workgroup per group of tiles, dense setup,
+//                        register/LDS binning, packed-FMA raster, 16-byte stores
+//   rasterChunkedKernel  worlds of more than 64 triangles: one workgroup per
+//                        tile, triangles through LDS in chunks of 64
+//   rasterBruteKernel    the round's first kernel (every triangle at every
+//                        pixel), kept as an on-device cross-check (variant 1)
+// Phases: S setup (lane = triangle: pose -> view-space vertices -> edge /
+// 1-over-depth / attribute planes, flat colour), binning (lane = triangle,
+// regions of the tile), R raster (lane = pixels, per-pixel z and winner in
+// VGPRs, triangle planes broadcast from LDS), O output (shade, 1/depth, store).
 //
-// The arithmetic restates DESIGN.md section 3 (S0-S9) op for op; the file is
-// compiled with -ffp-contract=off and fmaf appears only where the spec says so.
-// The CPU oracle (oracle/raster_oracle.c) is a separate restatement of the
-// same spec and is never linked here.
+// The file is compiled with -ffp-contract=off; fused multiply-adds appear only
+// where the spec writes fma().  The CPU oracle (oracle/raster_oracle.c) is a
+// separate restatement of the same spec and is never linked here.
 #include <hip/hip_runtime.h>
 
 #include "raster.hpp"
@@ -487,20 +489,14 @@ void rasterBruteKernel(const RasterParams p)
 }
 
 // ---------------------------------------------------------------------------
-// Variant 0 ("strip"): wave-level binning in registers.
-//
-// Lane k keeps triangle k's twelve plane coefficients in VGPRs after setup and
-// classifies the tile's sixteen 32x8-pixel regions against them (in-lane loop,
-// all triangles of the chunk at once): a region is dropped for the triangle
-// when one edge plane is negative, or the 1/depth plane is outside
-// (invFar, invNear], at the region pixel where that plane is largest /
-// smallest.  The planes are evaluated as fl(A*x + fl(B*y + C)), monotone in x
-// and in y, so the extreme over a region is the value at one of its corner
-// pixels and dropping the region cannot change any pixel: classification only
-// skips work.  The raster loop then runs per 64x16 band over the triangles
-// whose mask touches the band (ballot), pulls the coefficients of triangle k
-// into SGPRs with v_readlane (no LDS round trip) and rasterises the surviving
-// regions as straight-line code, four 8x8 blocks at a time, lane = pixel.
+// Wave-level binning.  The lane that set a triangle up classifies the tile's
+// sixteen 32x8-pixel regions against it: a region is dropped when one edge
+// plane is negative, or the 1/depth plane is outside (invFar, invNear], at the
+// region pixel where that plane is largest / smallest, or when it misses the
+// triangle's conservative bounding box.  The planes are evaluated as
+// fl(A*x + fl(B*y + C)), monotone in x and in y, so the extreme over a region
+// is the value at one of its corner pixels and dropping a region cannot change
+// any pixel: binning only skips work.
 // ---------------------------------------------------------------------------
 // S3-S7 for the lane's triangle; planes stay in registers, the shading record
 // goes to LDS.  Returns validity.
@@ -584,8 +580,6 @@ __device__ __forceinline__ uint32_t classifyRegions(const TriPlanes &c, const Ti
     return mask;
 }
 
-#define MRX_READLANE_F(v, k) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (k)))
-
 constexpr int kRegionBlocks = 4;    // a region is 32 x 8 pixels = 4 blocks of 8x8
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -656,36 +650,20 @@ __device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t
     }
 }
 
-// Shade + store a region.  A lane owns four consecutive pixels of one row
-// (pixel b of the lane is x = fx0 + b), so the common case is one 16-byte store
-// per output tensor per lane: eight lanes fill a 128-byte line, the wave writes
-// the region's 1 KiB of RGBA8 (and of depth) with a single instruction each.
-template <bool IDS, bool RESOLVED>
-__device__ __forceinline__ void outputRegion(const RasterParams &p, const WaveLdsCompact &L,
-                                             const TileCtx &t, uint32_t fx0, uint32_t fy,
-                                             const float (&px)[kRegionBlocks], float py,
-                                             float invFar, const float (&best)[kRegionBlocks],
-                                             const int32_t (&bid)[kRegionBlocks],
-                                             const uint32_t (&preRgba)[kRegionBlocks],
-                                             const int32_t (&preId)[kRegionBlocks])
+// Store a region whose pixels are already shaded (chunked kernel).  A lane owns
+// four consecutive pixels of one row (pixel b of the lane is x = fx0 + b), so
+// the common case is one 16-byte store per output tensor per lane.
+template <bool IDS>
+__device__ __forceinline__ void outputRegion(const RasterParams &p, const TileCtx &t,
+                                             uint32_t fx0, uint32_t fy, float invFar,
+                                             const float (&best)[kRegionBlocks],
+                                             const uint32_t (&rgba)[kRegionBlocks],
+                                             const int32_t (&id)[kRegionBlocks])
 {
-    uint32_t rgba[kRegionBlocks];
-    int32_t id[kRegionBlocks];
     float dep[kRegionBlocks];
 #pragma unroll
-    for (int b = 0; b < kRegionBlocks; ++b) {
-        rgba[b] = 0xFF000000u;
-        id[b] = -1;
-        if (RESOLVED) {
-            rgba[b] = preRgba[b];
-            id[b] = preId[b];
-        } else if (bid[b] >= 0) {
-            resolvePixel<IDS>(p, L, bid[b], best[b], px[b], py, rgba[b], id[b]);
-        }
-        // depth = 1/best: v_rcp_f32 (<= 1 ulp); the colour path uses the
-        // correctly rounded quotient where texel choice depends on it
+    for (int b = 0; b < kRegionBlocks; ++b)
         dep[b] = best[b] > invFar ? __builtin_amdgcn_rcpf(best[b]) : 0.0f;
-    }
     if (fy >= p.nslow || (p.debugSkip & 1u))
         return;
     const size_t o = ((size_t)t.view * p.nslow + fy) * p.nfast + fx0;
@@ -707,19 +685,22 @@ __device__ __forceinline__ void outputRegion(const RasterParams &p, const WaveLd
     }
 }
 
-// One workgroup = one 64x64 tile.  Wave 0 sets up and classifies the chunk's
-// triangles (lane = triangle) and publishes planes + region mask in LDS; after
-// the barrier every wave rasterises its own two 64x8 strips (four regions),
-// broadcasting triangle k's planes from LDS per visit, so the tile's triangles
-// are set up once while four times as many waves are in flight.
+// ---------------------------------------------------------------------------
+// Worlds with more than 64 triangles: one workgroup = one 64x64 tile, the
+// triangles go through LDS in chunks of 64.  Wave 0 sets up and classifies a
+// chunk (lane = triangle) and publishes planes + region mask; after the
+// barrier every wave rasterises its own two 64x8 strips against the chunk and
+// shades the chunk's winners before the next chunk replaces the records.
+// Correct and tested, not tuned: large meshes are BVH territory.
+// ---------------------------------------------------------------------------
 struct TileLds {
     float planes[kChunk][16];    // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | mask
     WaveLdsCompact rec;          // shading records
 };
 
-template <bool IDS, bool MULTI>
-__global__ __launch_bounds__(kWave *kWavesPerBlock, MULTI ? 3 : 8)
-void rasterStripKernel(const RasterParams p)
+template <bool IDS>
+__global__ __launch_bounds__(kWave *kWavesPerBlock, 3)
+void rasterChunkedKernel(const RasterParams p)
 {
     __shared__ TileLds lds;
     const int wave = threadIdx.x / kWave;
@@ -729,8 +710,6 @@ void rasterStripKernel(const RasterParams p)
     if (!tileSetup(p, blockIdx.x, lane, t, vc))
         return;                                   // whole workgroup leaves together
     const float invNear = p.invNear, invFar = p.invFar;
-    const uint32_t dummyRgba[kRegionBlocks] = { 0, 0, 0, 0 };
-    const int32_t dummyId[kRegionBlocks] = { 0, 0, 0, 0 };
 
     // per-wave pixel state: strips 2*wave and 2*wave+1, two regions each
     float best[4][kRegionBlocks];
@@ -747,8 +726,8 @@ void rasterStripKernel(const RasterParams p)
             outId[g][b] = -1;
         }
 
-    for (uint32_t chunk = 0; chunk == 0 || chunk < t.numTris; chunk += kChunk) {
-        if (MULTI && chunk != 0)
+    for (uint32_t chunk = 0; chunk < t.numTris; chunk += kChunk) {
+        if (chunk != 0)
             __syncthreads();                      // previous chunk fully consumed
         if (wave == 0) {
             TriPlanes c;
@@ -766,10 +745,6 @@ void rasterStripKernel(const RasterParams p)
 
         // lane k looks at triangle k's region mask; planes are read per visit
         const uint32_t mask = __float_as_uint(lds.planes[lane][12]);
-        // every surviving triangle stays behind the near plane over the whole
-        // tile: the per-pixel near test is dropped
-        const bool nearFree = __ballot(mask != 0 && !(mask & kNearFree)) == 0;
-
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int strip = 2 * wave + (g >> 1), hf = g & 1;
@@ -781,53 +756,38 @@ void rasterStripKernel(const RasterParams p)
             for (int b = 0; b < kRegionBlocks; ++b)
                 px[b] = (float)(fx0 + b);
             const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
-            if (!(p.debugSkip & 2u)) {
-                if (nearFree)
-                    rasterRegion<false, 0>(lds.planes, act, px, py, invNear, best[g], bid[g]);
-                else
-                    rasterRegion<true, 0>(lds.planes, act, px, py, invNear, best[g], bid[g]);
-            }
-            if (MULTI) {
-                // shade this chunk's winners before its records are replaced
+            if (!(p.debugSkip & 2u))
+                rasterRegion<true, 0>(lds.planes, act, px, py, invNear, best[g], bid[g]);
+            // shade this chunk's winners before its records are replaced
 #pragma unroll
-                for (int b = 0; b < kRegionBlocks; ++b) {
-                    if (bid[g][b] >= 0)
-                        resolvePixel<IDS>(p, lds.rec, bid[g][b], best[g][b], px[b], py,
-                                          outRgba[g][b], outId[g][b]);
-                    bid[g][b] = -1;
-                }
-            } else {
-                outputRegion<IDS, false>(p, lds.rec, t, fx0, fy, px, py, invFar, best[g], bid[g],
-                                         dummyRgba, dummyId);
+            for (int b = 0; b < kRegionBlocks; ++b) {
+                if (bid[g][b] >= 0)
+                    resolvePixel<IDS>(p, lds.rec, bid[g][b], best[g][b], px[b], py,
+                                      outRgba[g][b], outId[g][b]);
+                bid[g][b] = -1;
             }
         }
-        if (!MULTI)
-            break;
     }
 
-    if (MULTI) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int strip = 2 * wave + (g >> 1), hf = g & 1;
-            const uint32_t fy = t.tileY0 + strip * 8 + t.ly;
-            const uint32_t fx0 = t.tileX0 + hf * 32 + 4 * t.lx;
-            float px[kRegionBlocks];
-#pragma unroll
-            for (int b = 0; b < kRegionBlocks; ++b)
-                px[b] = (float)(fx0 + b);
-            outputRegion<IDS, true>(p, lds.rec, t, fx0, fy, px, (float)fy, invFar, best[g], bid[g],
-                                    outRgba[g], outId[g]);
-        }
+    for (int g = 0; g < 4; ++g) {
+        const int strip = 2 * wave + (g >> 1), hf = g & 1;
+        const uint32_t fy = t.tileY0 + strip * 8 + t.ly;
+        const uint32_t fx0 = t.tileX0 + hf * 32 + 4 * t.lx;
+        outputRegion<IDS>(p, t, fx0, fy, invFar, best[g], outRgba[g], outId[g]);
     }
 }
 
 // ---------------------------------------------------------------------------
-// Variant 0, worlds of at most 64 triangles: one workgroup renders a group of
-// G = 64 / SLOTS consecutive tiles.  Wave 0 sets up and classifies the
-// triangles of all G tiles in ONE pass (lane = tile j, triangle slot k: dense
-// lanes instead of 14-of-64), publishes planes / masks / shading records in
-// LDS; after the barrier the four waves walk the G tiles, each wave rastering
-// its own two 64x8 strips of every tile.
+// Worlds of at most 64 triangles (every BASELINE scene): one workgroup renders
+// a group of G = 64 / SLOTS consecutive tiles.
+//   S1  wave 0 sets up the triangles of all G tiles in ONE pass (lane = tile
+//       j, triangle slot k: dense lanes instead of 14-of-64) and publishes
+//       planes, bounding boxes and shading records in LDS;
+//   S2  waves 0-3 each classify four of the sixteen regions of every
+//       triangle (lane = the same (j, k)), OR-ing the bits into LDS;
+//   R+O all waves pull (tile, strip) items off an LDS counter, rasterise the
+//       strip's two regions and store them.
 // ---------------------------------------------------------------------------
 constexpr int kBackground = kChunk;   // record index of "nothing hit"
 
@@ -839,7 +799,7 @@ struct GroupLds {
     uint32_t tileInfo[4][4];            // per tile of the group: view, x0, y0, flags
     uint32_t nextItem;                  // (tile, strip) work counter of phase R
 };
-constexpr uint32_t kTileAnyTex = 1u, kTileNearFree = 2u, kTileValid = 4u;
+constexpr uint32_t kTileValid = 4u;
 
 __device__ __forceinline__ const float *shadeRec(const GroupLds &L, int32_t w) { return L.shade[w]; }
 
@@ -1179,8 +1139,8 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         }
     } else if (multi) {
         // more than one chunk of triangles per world: one workgroup per tile
-        if (ids) rasterStripKernel<true, true><<<dim3(items), block, 0, stream>>>(p);
-        else     rasterStripKernel<false, true><<<dim3(items), block, 0, stream>>>(p);
+        if (ids) rasterChunkedKernel<true><<<dim3(items), block, 0, stream>>>(p);
+        else     rasterChunkedKernel<false><<<dim3(items), block, 0, stream>>>(p);
     } else {
         // dense setup: 64 / SLOTS tiles per workgroup
         int slots = maxWorldTris <= 16 ? 16 : maxWorldTris <= 32 ? 32 : 64;
