@@ -43,6 +43,9 @@ def test_reference_demo_scene(native, mode):
     dict(num_worlds=8, width=96, height=40),            # ragged tiles
     dict(num_worlds=8, width=32, height=32),            # smaller than a tile
     dict(num_worlds=4, width=200, height=72, textured=True),
+    dict(num_worlds=6, width=50, height=30),            # width % 4 != 0: scalar stores
+    dict(num_worlds=3, width=33, height=33, textured=True, render_mode="Raytracer"),
+    dict(num_worlds=130, width=64, height=64, with_wall=True),   # ragged last tile group
     dict(num_worlds=8, width=256, height=256, textured=True, render_mode="Raytracer"),
     dict(num_worlds=5, width=80, height=80, with_wall=True, render_mode="Raytracer"),
 ], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
@@ -201,6 +204,23 @@ def test_back_face_culling_cases(native):
     _, got, ref = _parity(d)
     assert got["rgb"].shape[0] == 8
     assert (got["tri_id"][1] >= 0).all()        # eye inside the cube: walls everywhere
+
+
+def test_zero_worlds_and_zero_views(native):
+    d = scenes.synthetic_scene(2)
+    d.worlds = []
+    d.num_worlds = 0
+    r = make_product(d)
+    r.step()
+    r.sync()
+    assert tuple(r.rgb_tensor().shape) == (0, 64, 64, 4)
+    d = scenes.synthetic_scene(2)
+    d.worlds = [(2, 0, 0, 0), (2, 2, 0, 0)]       # instances but no cameras
+    r = make_product(d)
+    r.step()
+    r.sync()
+    assert tuple(r.depth_tensor().shape) == (0, 64, 64, 1)
+    assert tuple(r.instance_position_tensor().shape) == (4, 3)
 
 
 def test_error_behaviour(native):
