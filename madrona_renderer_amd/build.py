@@ -109,10 +109,31 @@ def build_module(force=False, verbose=False):
     return out
 
 
+def headless_path():
+    return os.path.join(HERE, "renderer_headless")
+
+
+def build_headless(force=False, verbose=False):
+    """The reference's headless CLI (src/headless.cpp) over the MI355X Manager."""
+    out = headless_path()
+    deps = ["headless.cpp", "assets.cpp", "assets.hpp"] + MGR_DEPS
+    if force or _stale(out, deps) or os.path.getmtime(out) < os.path.getmtime(lib_path()):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__",
+               "-I/opt/rocm/include",
+               "-DMRX_DATA_DIR=\"%s\"" % os.path.join(ROOT, "data"),
+               os.path.join(CSRC, "headless.cpp"), os.path.join(CSRC, "manager.cpp"),
+               os.path.join(CSRC, "assets.cpp"),
+               "-L" + HERE, "-lmrx_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+        _run(cmd, verbose)
+    return out
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_manager(force, verbose)
     build_module(force, verbose)
+    build_headless(force, verbose)
     return lib_path(), mgr_path(), module_path()
 
 

@@ -328,6 +328,59 @@ bool decodePNGMem(const uint8_t *data, size_t size, Image &out, std::string &err
     return true;
 }
 
+namespace {
+void putChunk(std::vector<uint8_t> &out, const char type[4], const uint8_t *body, uint32_t len)
+{
+    const uint8_t hdr[4] = { (uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8),
+                             (uint8_t)len };
+    out.insert(out.end(), hdr, hdr + 4);
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    if (len)
+        out.insert(out.end(), body, body + len);
+    const uint32_t crc = (uint32_t)crc32(0L, out.data() + at, (uInt)(len + 4));
+    const uint8_t tail[4] = { (uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8),
+                              (uint8_t)crc };
+    out.insert(out.end(), tail, tail + 4);
+}
+}  // namespace
+
+bool encodePNG(const std::string &path, const uint8_t *rgba, uint32_t width, uint32_t height,
+               std::string &err)
+{
+    std::vector<uint8_t> raw((size_t)height * ((size_t)width * 4 + 1));
+    for (uint32_t y = 0; y < height; ++y) {
+        uint8_t *line = raw.data() + (size_t)y * ((size_t)width * 4 + 1);
+        line[0] = 0;
+        std::memcpy(line + 1, rgba + (size_t)y * width * 4, (size_t)width * 4);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) {
+        err = "PNG deflate failed";
+        return false;
+    }
+    std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    const uint8_t ihdr[13] = { (uint8_t)(width >> 24), (uint8_t)(width >> 16), (uint8_t)(width >> 8),
+                               (uint8_t)width, (uint8_t)(height >> 24), (uint8_t)(height >> 16),
+                               (uint8_t)(height >> 8), (uint8_t)height, 8, 6, 0, 0, 0 };
+    putChunk(out, "IHDR", ihdr, 13);
+    putChunk(out, "IDAT", z.data(), (uint32_t)zlen);
+    putChunk(out, "IEND", nullptr, 0);
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) {
+        err = "cannot write '" + path + "'";
+        return false;
+    }
+    const size_t put = std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    if (put != out.size()) {
+        err = "short write on '" + path + "'";
+        return false;
+    }
+    return true;
+}
+
 bool decodePNG(const std::string &path, Image &out, std::string &err)
 {
     std::vector<uint8_t> file;

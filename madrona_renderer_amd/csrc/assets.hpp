@@ -26,5 +26,8 @@ struct Image {
 bool loadOBJ(const std::string &path, TriSoup &out, std::string &err);
 bool decodePNG(const std::string &path, Image &out, std::string &err);
 bool decodePNGMem(const uint8_t *data, size_t size, Image &out, std::string &err);
+// 8-bit RGBA, non-interlaced, zlib-deflated, filter type 0 on every scanline.
+bool encodePNG(const std::string &path, const uint8_t *rgba, uint32_t width, uint32_t height,
+               std::string &err);
 
 }  // namespace mrx

@@ -921,10 +921,17 @@ void rasterGroupKernel(const RasterParams p)
         const uint32_t item = item0 + j;
         const bool tileOk = item < numItems;
         TileCtx t;
-        t.view = tileOk ? (tilesPerView == 1 ? item : item / tilesPerView) : 0u;
-        const uint32_t tile = tilesPerView == 1 ? 0u : item - t.view * tilesPerView;
-        t.tileX0 = (tile % p.tilesFast) * 64u;
-        t.tileY0 = (tile / p.tilesFast) * 64u;
+        // integer divisions cost ~25 VALU each: real (scalar) branches around
+        // them for the common one-tile-per-view / one-camera-per-world cases
+        t.view = tileOk ? item : 0u;
+        t.tileX0 = t.tileY0 = 0u;
+        if (tilesPerView != 1) {
+            t.view = tileOk ? item / tilesPerView : 0u;
+            const uint32_t tile = tileOk ? item - t.view * tilesPerView : 0u;
+            const uint32_t ty = tile / p.tilesFast;
+            t.tileX0 = (tile - ty * p.tilesFast) * 64u;
+            t.tileY0 = ty * 64u;
+        }
         t.triBegin = t.view * p.viewTriStride;
         t.lx = t.ly = 0;
         // everything addressed by the view index is requested up front; the
@@ -939,7 +946,10 @@ void rasterGroupKernel(const RasterParams p)
                                : li == 2 ? p.uniPrefix[2] : p.uniPrefix[3];
             const uint32_t first = li == 0 ? p.uniFirstTri[0] : li == 1 ? p.uniFirstTri[1]
                                  : li == 2 ? p.uniFirstTri[2] : p.uniFirstTri[3];
-            wt.inst = (t.view / p.uniCamsPerWorld) * p.uniInstances + li;
+            uint32_t world = t.view;
+            if (p.uniCamsPerWorld != 1)
+                world = t.view / p.uniCamsPerWorld;
+            wt.inst = world * p.uniInstances + li;
             wt.tri = first + (kk - pre);
             t.numTris = tileOk ? p.uniPrefix[4] : 0u;
             if (kk >= p.uniPrefix[4]) {           // idle slot: keep the loads in range
