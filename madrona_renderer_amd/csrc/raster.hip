@@ -228,13 +228,16 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
         out.Dy = tr ? ax : az;
         out.Dc = ((nn[0] * p.ox + nn[1]) + nn[2] * p.oz) * rd;
     }
-    const float rad = fabsf(rd);
-    cold[0] = ((uv[0] * A[0] + uv[2] * A[1]) + uv[4] * A[2]) * rad;
-    cold[1] = ((uv[0] * B[0] + uv[2] * B[1]) + uv[4] * B[2]) * rad;
-    cold[2] = ((uv[0] * C[0] + uv[2] * C[1]) + uv[4] * C[2]) * rad;
-    cold[3] = ((uv[1] * A[0] + uv[3] * A[1]) + uv[5] * A[2]) * rad;
-    cold[4] = ((uv[1] * B[0] + uv[3] * B[1]) + uv[5] * B[2]) * rad;
-    cold[5] = ((uv[1] * C[0] + uv[3] * C[1]) + uv[5] * C[2]) * rad;
+    // u/v planes (S8) are only ever read for textured triangles
+    if (tex >= 0) {
+        const float rad = fabsf(rd);
+        cold[0] = ((uv[0] * A[0] + uv[2] * A[1]) + uv[4] * A[2]) * rad;
+        cold[1] = ((uv[0] * B[0] + uv[2] * B[1]) + uv[4] * B[2]) * rad;
+        cold[2] = ((uv[0] * C[0] + uv[2] * C[1]) + uv[4] * C[2]) * rad;
+        cold[3] = ((uv[1] * A[0] + uv[3] * A[1]) + uv[5] * A[2]) * rad;
+        cold[4] = ((uv[1] * B[0] + uv[3] * B[1]) + uv[5] * B[2]) * rad;
+        cold[5] = ((uv[1] * C[0] + uv[3] * C[1]) + uv[5] * C[2]) * rad;
+    }
 
     __builtin_amdgcn_sched_barrier(0);
     // S7: flat two-sided Lambert
