@@ -166,6 +166,11 @@ int mrx_sync(mrx_renderer *r);
 void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim,
                  int *dtype, int *device);
 
+/* -- debug readback: waits for the stream, then copies the first `bytes`
+ *    bytes of a buffer to host memory (what /root/reference/src/dump.cpp:53-70
+ *    does with cudaMemcpy). */
+int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes);
+
 int mrx_info(mrx_renderer *r, mrx_info_t *out);
 void *mrx_stream(mrx_renderer *r);
 

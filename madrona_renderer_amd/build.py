@@ -118,13 +118,11 @@ def build_headless(force=False, verbose=False):
     out = headless_path()
     deps = ["headless.cpp", "assets.cpp", "assets.hpp"] + MGR_DEPS
     if force or _stale(out, deps) or os.path.getmtime(out) < os.path.getmtime(lib_path()):
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__",
-               "-I/opt/rocm/include",
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall",
                "-DMRX_DATA_DIR=\"%s\"" % os.path.join(ROOT, "data"),
                os.path.join(CSRC, "headless.cpp"), os.path.join(CSRC, "manager.cpp"),
                os.path.join(CSRC, "assets.cpp"),
-               "-L" + HERE, "-lmrx_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
-               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+               "-L" + HERE, "-lmrx_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-o", out]
         _run(cmd, verbose)
     return out
 

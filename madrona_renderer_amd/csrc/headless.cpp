@@ -20,9 +20,8 @@
 #include <string>
 #include <vector>
 
-#include <hip/hip_runtime_api.h>
-
 #include "../../include/madrona_mi355/manager.hpp"
+#include "../../include/mrx.h"
 #include "assets.hpp"
 
 #ifndef MRX_DATA_DIR
@@ -190,13 +189,16 @@ void buildDemo(Scene &s, uint32_t n, const std::string &dataDir)
 // Tiled dump, as /root/reference/src/dump.cpp:45-119: ceil(sqrt(N)) rows of
 // images; depth as grey 255 * min(d / 255, 1).  Raytracer storage is [x][y]
 // and is transposed back (dump.cpp:9-21); rasterizer storage is row-major.
-bool dumpTiled(const std::string &name, const void *devPtr, uint32_t numImages, uint32_t resX,
+bool dumpTiled(const std::string &name, Manager &mgr, uint32_t numImages, uint32_t resX,
                uint32_t resY, bool depth, bool transpose)
 {
     const size_t bytesPerImage = (size_t)4 * resX * resY;
     std::vector<uint8_t> host(bytesPerImage * numImages);
-    if (hipMemcpy(host.data(), devPtr, host.size(), hipMemcpyDeviceToHost) != hipSuccess)
+    if (mrx_copy_to_host((mrx_renderer *)mgr.nativeHandle(), depth ? MRX_BUF_DEPTH : MRX_BUF_RGB,
+                         host.data(), host.size()) != MRX_OK) {
+        std::fprintf(stderr, "%s\n", mrx_last_error());
         return false;
+    }
     const uint32_t tilesY = (uint32_t)std::ceil(std::sqrt((double)numImages));
     const uint32_t tilesX = (uint32_t)std::ceil((double)numImages / tilesY);
     const uint32_t outW = tilesX * resX, outH = tilesY * resY;
@@ -280,9 +282,7 @@ int main(int argc, char **argv)
     if (args.dump) {
         const bool rt = args.mode == Mode::Raycaster;
         const uint32_t resY = rt ? args.width : args.height;
-        const void *ptr = args.dumpDepth ? (const void *)mgr.depthCudaPtr()
-                                         : (const void *)mgr.rgbCudaPtr();
-        if (!dumpTiled(args.outName, ptr, args.numWorlds, args.width, resY, args.dumpDepth, rt))
+        if (!dumpTiled(args.outName, mgr, args.numWorlds, args.width, resY, args.dumpDepth, rt))
             return EXIT_FAILURE;
     }
 

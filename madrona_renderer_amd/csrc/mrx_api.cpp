@@ -623,6 +623,26 @@ void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dt
     return ptr;
 }
 
+int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes)
+{
+    if (!r || !dst)
+        return fail(MRX_E_INVALID, "null argument");
+    int64_t dims[4] = { 1, 1, 1, 1 };
+    int nd = 0, dt = 0, dev = 0;
+    void *src = mrx_buffer(r, which, dims, &nd, &dt, &dev);
+    if (!src)
+        return MRX_E_UNSUPPORTED;
+    uint64_t total = dt == MRX_DTYPE_U8 ? 1 : 4;
+    for (int i = 0; i < nd; ++i)
+        total *= (uint64_t)dims[i];
+    if (bytes > total)
+        return fail(MRX_E_INVALID, "readback larger than the buffer");
+    MRX_HIP(hipSetDevice(r->device));
+    MRX_HIP(hipStreamSynchronize(r->stream));
+    MRX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MRX_OK;
+}
+
 int mrx_info(mrx_renderer *r, mrx_info_t *out)
 {
     if (!r || !out)
