@@ -125,7 +125,6 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     for (int r = 0; r < 3; ++r)
         tv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r], dt[0], dt[1], dt[2]);
 
-    __builtin_amdgcn_sched_barrier(0);
     const float4 *src = reinterpret_cast<const float4 *>(p.tris + wt.tri);
     const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
     const float4 *msrc = reinterpret_cast<const float4 *>(p.triMats + wt.tri);
@@ -160,7 +159,6 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
             P[j][r] = dot3(MV[r][0], MV[r][1], MV[r][2],
                            op[3 * j], op[3 * j + 1], op[3 * j + 2]) + tv[r];
 
-    __builtin_amdgcn_sched_barrier(0);
     float N[3][3], e1[3], e2[3], nn[3];
     cross3(P[1], P[2], N[0]);
     cross3(P[2], P[0], N[1]);
@@ -175,7 +173,6 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     // S6: degenerate / edge-on triangles; S6b: faces of a closed object turned
     // away from an eye outside the object can never be the nearest hit
     const bool valid = fabsf(d) > 0.0f && !(cullBack && d > 0.0f) && !(cullFront && d < 0.0f);
-    __builtin_amdgcn_sched_barrier(0);
 
     // Binning aid: pixel-space bounding box of the projected vertices, padded
     // by a pixel plus a relative margin that swallows the rounding of the
@@ -206,7 +203,6 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     const float flip = d < 0.0f ? -1.0f : 1.0f;
     const bool tr = p.transposed != 0;
 
-    __builtin_amdgcn_sched_barrier(0);
     float A[3], B[3], C[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
@@ -239,7 +235,6 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
         cold[5] = ((uv[1] * C[0] + uv[3] * C[1]) + uv[5] * C[2]) * rad;
     }
 
-    __builtin_amdgcn_sched_barrier(0);
     // S7: flat two-sided Lambert
     const float len = sqrtf(dot3(nn[0], nn[1], nn[2], nn[0], nn[1], nn[2]));
     float ndl = dot3(nn[0], nn[1], nn[2], vc.lv[0], vc.lv[1], vc.lv[2]) / len;
