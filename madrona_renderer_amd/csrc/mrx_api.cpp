@@ -480,6 +480,14 @@ int mrx_create(const mrx_config *cfg, mrx_renderer **out)
         return fail(MRX_E_INVALID, "bad view size");
     if (cfg->num_worlds && !cfg->worlds)
         return fail(MRX_E_INVALID, "worlds is null");
+    if ((cfg->num_instances && !cfg->instances) || (cfg->num_cameras && !cfg->cameras) ||
+        (cfg->num_asset_paths && !cfg->asset_paths) || (cfg->num_materials && !cfg->materials) ||
+        (cfg->num_textures && !cfg->texture_paths))
+        return fail(MRX_E_INVALID, "a table pointer is null while its count is not zero");
+    if (cfg->geo.num_meshes &&
+        (!cfg->geo.vertices || !cfg->geo.uvs || !cfg->geo.indices || !cfg->geo.mesh_vertex_offsets ||
+         !cfg->geo.mesh_index_offsets || !cfg->geo.mesh_materials))
+        return fail(MRX_E_INVALID, "raw geometry arrays are null while num_meshes is not zero");
     if (cfg->kernel_variant < 0 || cfg->kernel_variant >= mrx::kNumVariants)
         return fail(MRX_E_INVALID, "bad kernel_variant");
     int ndev = 0;

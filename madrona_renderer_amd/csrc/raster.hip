@@ -904,6 +904,8 @@ void rasterGroupKernel(const RasterParams p)
     const uint32_t numItems = p.numViews * tilesPerView;
     const uint32_t item0 = blockIdx.x * G;
     const float invNear = p.invNear, invFar = p.invFar;
+    if (p.debugSkip & 16u)
+        return;                                   // timing aid: bare launch
     unsigned long long *stamps = (p.debugStamps && wave < 4)
         ? p.debugStamps + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
 #define MRX_STAMP(i)                                                           \

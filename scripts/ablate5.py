@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madrona_renderer_amd import scenes
 desc = scenes.synthetic_scene(4096)
-for skip in (0, 2, 6, 14, 1, 3, 15):
+for skip in (0, 2, 6, 14, 1, 3, 15, 31):
     os.environ["MRX_DEBUG_SKIP"] = str(skip)
     r = scenes.make_renderer(desc)
     r.time_renders(20)
