@@ -21,6 +21,18 @@ _MODULE = None
 _CAPI = None
 
 
+def _torch_first():
+    """PyTorch-ROCm ships its own libamdhip64; libmrx_hip.so links the system
+    one.  Whichever is loaded first serves both (same SONAME), and torch fails
+    to initialise ("No HIP GPUs are available") when it finds the other copy
+    already resident -- so torch, when present, is imported before the native
+    library is mapped."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib_path():
     return _build.lib_path()
 
@@ -35,6 +47,7 @@ def load_module():
     global _MODULE
     if _MODULE is not None:
         return _MODULE
+    _torch_first()
     path = module_path()
     if not os.path.exists(path):
         raise ImportError(
@@ -53,6 +66,7 @@ def load_capi():
     """ctypes handle on libmrx_hip.so (the C-ABI of include/mrx.h)."""
     global _CAPI
     if _CAPI is None:
+        _torch_first()
         path = lib_path()
         if not os.path.exists(path):
             raise ImportError("native library %s is missing (build it with hipcc)" % path)

@@ -957,7 +957,8 @@ void rasterGroupKernel(const RasterParams p)
                 wt.tri = 0;
             }
         } else {
-            wt = p.viewTris[t.triBegin + k];
+            // slots past the view's row are idle: keep their load inside the row
+            wt = p.viewTris[t.triBegin + ((uint32_t)k < p.viewTriStride ? (uint32_t)k : 0u)];
             t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
         }
         ViewConst vc;

@@ -1,0 +1,84 @@
+"""Randomised parity: raw-geometry scenes with triangles at every scale and
+orientation -- crossing the eye plane, edge-on, far outside the frustum,
+sub-pixel, coincident -- rendered by the HIP path and by the oracle must agree
+bit for bit (visibility, colour) and to 1e-4 in depth."""
+import numpy as np
+import pytest
+
+from madrona_renderer_amd import scenes
+from tests.util import assert_parity, fetch, make_product, render_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return tuple(float(np.float32(x)) for x in q)
+
+
+def _scene(seed, num_worlds, width, height, mode):
+    rng = np.random.default_rng(seed)
+    verts, uvs, idx, voff, ioff, mats = [], [], [], [], [], []
+    n_mesh = int(rng.integers(2, 6))
+    for m in range(n_mesh):
+        voff.append(len(verts))
+        ioff.append(len(idx))
+        scale = 10.0 ** rng.uniform(-2, 2)
+        nv = int(rng.integers(3, 12))
+        v = rng.normal(size=(nv, 3)) * scale
+        if m == 0:                                   # a few exact duplicates / degenerate tris
+            v[1] = v[0]
+        verts += v.tolist()
+        uvs += rng.uniform(-2, 3, size=(nv, 2)).tolist()
+        nt = int(rng.integers(1, 9))
+        idx += rng.integers(0, nv, size=3 * nt).tolist()
+        mats.append(int(rng.integers(-1, 3)))
+    instances, cameras, worlds = [], [], []
+    for w in range(num_worlds):
+        ni = int(rng.integers(0, 5))
+        for _ in range(ni):
+            pos = tuple(float(np.float32(x)) for x in rng.normal(size=3) * 10.0 ** rng.uniform(-1, 1.5))
+            s = tuple(float(np.float32(x)) for x in rng.uniform(-2, 2, size=3))
+            instances.append((pos, _random_quat(rng), s, int(rng.integers(0, n_mesh + 1))))
+        nc = int(rng.integers(1, 3))
+        for c in range(nc):
+            cpos = tuple(float(np.float32(x)) for x in rng.normal(size=3) * 5.0)
+            if ni and c == 0:
+                # first camera looks at one of the world's instances (often from
+                # very close: triangles cross the eye plane); the second is random
+                tgt = np.asarray(instances[-1 - int(rng.integers(0, ni))][0]) + rng.normal(size=3) * 0.3
+                cameras.append((cpos, scenes.look_at(cpos, tgt)))
+            else:
+                cameras.append((cpos, _random_quat(rng)))
+        worlds.append((ni, len(instances) - ni, nc, len(cameras) - nc))
+    import os
+    return scenes.SceneDesc(
+        num_worlds=num_worlds, render_mode=mode, width=width, height=height,
+        mesh_vertices=np.asarray(verts, np.float32), mesh_uvs=np.asarray(uvs, np.float32),
+        mesh_indices=np.asarray(idx, np.uint32), mesh_vertex_offsets=np.asarray(voff, np.uint32),
+        mesh_indices_offsets=np.asarray(ioff, np.uint32), mesh_materials=np.asarray(mats, np.int32),
+        materials=[((0.9, 0.5, 0.2, 1.0), -1, 0.5, 0.5), ((0.4, 0.7, 1.0, 1.0), 0, 0.5, 0.5),
+                   ((1.0, 1.0, 1.0, 1.0), 5, 0.5, 0.5)],        # texture 5 does not exist
+        texture_paths=[os.path.join(scenes.DATA_DIR, "cube.png")],
+        instances=instances, cameras=cameras, worlds=worlds)
+
+
+@pytest.mark.parametrize("seed,size,mode", [
+    (1, (64, 64), "Rasterizer"), (2, (64, 64), "Rasterizer"), (3, (96, 48), "Rasterizer"),
+    (4, (37, 53), "Rasterizer"), (5, (64, 64), "Raytracer"), (6, (100, 100), "Raytracer"),
+    (7, (128, 64), "Rasterizer"), (8, (64, 64), "Rasterizer"),
+])
+def test_random_raw_geometry_scenes(native, seed, size, mode):
+    d = _scene(seed, num_worlds=24, width=size[0], height=size[1], mode=mode)
+    r = make_product(d, visibility=True)
+    got = fetch(r)
+    ref = render_oracle(d)
+    assert_parity(got, ref)
+    assert (ref["tri_id"] >= 0).mean() > 0.01          # the scenes do draw something
+
+
+def test_random_scene_on_brute_variant_too(native):
+    d = _scene(11, num_worlds=16, width=64, height=64, mode="Rasterizer")
+    r = make_product(d, visibility=True, variant=1)
+    assert_parity(fetch(r), render_oracle(d))
