@@ -50,6 +50,21 @@ struct Corner {
     int vt;  // -1: none
 };
 
+std::string dirOf(const std::string &path)
+{
+    const size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? std::string() : path.substr(0, slash + 1);
+}
+
+// rest of the line, trimmed
+std::string restOfLine(const char *p, const char *eol)
+{
+    while (p < eol && (*p == ' ' || *p == '\t')) ++p;
+    const char *e = eol;
+    while (e > p && (e[-1] == ' ' || e[-1] == '\t' || e[-1] == '\r' || e[-1] == '\n')) --e;
+    return std::string(p, e);
+}
+
 }  // namespace
 
 bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
@@ -64,6 +79,10 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
     std::vector<Corner> corners;
     out.pos.clear();
     out.uv.clear();
+    out.triMtl.clear();
+    out.mtlNames.clear();
+    out.mtlLibs.clear();
+    int32_t curMtl = -1;
 
     const char *p = (const char *)file.data();
     int lineNo = 0;
@@ -132,7 +151,56 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
                     out.uv.push_back(c.vt >= 0 ? vts[2 * c.vt + 0] : 0.0f);
                     out.uv.push_back(c.vt >= 0 ? vts[2 * c.vt + 1] : 0.0f);
                 }
+                out.triMtl.push_back(curMtl);
             }
+        } else if (!std::strncmp(p, "usemtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
+            const std::string name = restOfLine(p + 6, eol);
+            curMtl = -1;
+            for (size_t i = 0; i < out.mtlNames.size(); ++i)
+                if (out.mtlNames[i] == name)
+                    curMtl = (int32_t)i;
+            if (curMtl < 0) {
+                curMtl = (int32_t)out.mtlNames.size();
+                out.mtlNames.push_back(name);
+            }
+        } else if (!std::strncmp(p, "mtllib", 6) && (p[6] == ' ' || p[6] == '\t')) {
+            const std::string name = restOfLine(p + 6, eol);
+            if (!name.empty())
+                out.mtlLibs.push_back(name[0] == '/' ? name : dirOf(path) + name);
+        }
+        p = eol + 1;
+    }
+    return true;
+}
+
+bool loadMTL(const std::string &path, std::vector<MtlMaterial> &out, std::string &err)
+{
+    std::vector<uint8_t> file;
+    if (!readFile(path, file, err))
+        return false;
+    file.push_back('\n');
+    file.push_back(0);
+    const char *p = (const char *)file.data();
+    while (*p) {
+        const char *eol = std::strchr(p, '\n');
+        skipSpace(p);
+        if (!std::strncmp(p, "newmtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
+            out.emplace_back();
+            out.back().name = restOfLine(p + 6, eol);
+        } else if (!out.empty() && p[0] == 'K' && p[1] == 'd' && (p[2] == ' ' || p[2] == '\t')) {
+            const char *q = p + 2;
+            for (int i = 0; i < 3; ++i) {
+                skipSpace(q);
+                out.back().kd[i] = parseFloat(q);
+            }
+        } else if (!out.empty() && !std::strncmp(p, "map_Kd", 6) && (p[6] == ' ' || p[6] == '\t')) {
+            // options (-s, -o ...) are not supported: the last token is the file
+            std::string rest = restOfLine(p + 6, eol);
+            const size_t sp = rest.find_last_of(" \t");
+            if (sp != std::string::npos)
+                rest = rest.substr(sp + 1);
+            if (!rest.empty())
+                out.back().mapKd = rest[0] == '/' ? rest : dirOf(path) + rest;
         }
         p = eol + 1;
     }

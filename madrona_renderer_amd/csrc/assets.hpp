@@ -14,7 +14,18 @@ namespace mrx {
 struct TriSoup {
     std::vector<float> pos;  // [T][3 verts][xyz]
     std::vector<float> uv;   // [T][3 verts][uv]
+    // `usemtl` of each triangle as an index into mtlNames, -1 = none
+    std::vector<int32_t> triMtl;
+    std::vector<std::string> mtlNames;
+    std::vector<std::string> mtlLibs;   // `mtllib` files, resolved against the OBJ's directory
     uint32_t numTris() const { return (uint32_t)(pos.size() / 9); }
+};
+
+// One `newmtl` block of a Wavefront MTL file (the subset this renderer shades with).
+struct MtlMaterial {
+    std::string name;
+    float kd[3] = { 1.0f, 1.0f, 1.0f };
+    std::string mapKd;                  // resolved against the MTL's directory, "" = none
 };
 
 struct Image {
@@ -24,6 +35,7 @@ struct Image {
 
 // Both return false and fill `err` on failure.
 bool loadOBJ(const std::string &path, TriSoup &out, std::string &err);
+bool loadMTL(const std::string &path, std::vector<MtlMaterial> &out, std::string &err);
 bool decodePNG(const std::string &path, Image &out, std::string &err);
 bool decodePNGMem(const uint8_t *data, size_t size, Image &out, std::string &err);
 // 8-bit RGBA, non-interlaced, zlib-deflated, filter type 0 on every scanline.

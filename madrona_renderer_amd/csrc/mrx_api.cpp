@@ -170,6 +170,13 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             tris.push_back(o);
         }
     };
+    // File materials (MTL) are appended after the API materials and textures:
+    // an asset with mat_id >= 0 is drawn with that API material; with mat_id
+    // -1 each face keeps the material its OBJ names through mtllib / usemtl
+    // (Kd colour, map_Kd PNG texture), or the default when it names none.
+    struct FileMat { float kd[3]; std::string mapKd; };
+    std::vector<FileMat> fileMats;
+    std::vector<std::string> fileTexPaths;
     for (uint32_t a = 0; a < cfg.num_asset_paths; ++a) {
         TriSoup soup;
         std::string err;
@@ -177,12 +184,30 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             return fail(MRX_E_ASSET, "Failed to load render assets: " + err);
         // The reference carries a per-asset material id through its API
         // (bindings.cpp:26-36) but applies it only inside a disabled block
-        // (mgr.cpp:339-349); the block's evident intent is implemented here:
-        // mat_id indexes the additional materials, -1 leaves the default.
+        // (mgr.cpp:339-349); the block's evident intent is implemented here.
         int32_t mat = -1;
         if (cfg.mat_assignments && a < cfg.num_mat_assignments)
             mat = cfg.mat_assignments[a];
         appendObject(soup.pos.data(), soup.uv.data(), soup.numTris(), mat);
+        if (mat < 0 && !soup.mtlNames.empty()) {
+            std::vector<MtlMaterial> lib;
+            for (const std::string &ml : soup.mtlLibs) {
+                std::string merr;
+                (void)loadMTL(ml, lib, merr);       // a missing library leaves faces on the default
+            }
+            std::vector<int32_t> nameToMat(soup.mtlNames.size(), -1);
+            for (size_t n = 0; n < soup.mtlNames.size(); ++n)
+                for (const MtlMaterial &mm : lib)
+                    if (mm.name == soup.mtlNames[n]) {
+                        nameToMat[n] = (int32_t)(cfg.num_materials + fileMats.size());
+                        fileMats.push_back(FileMat { { mm.kd[0], mm.kd[1], mm.kd[2] }, mm.mapKd });
+                        break;
+                    }
+            const size_t first = tris.size() - soup.numTris();
+            for (uint32_t t = 0; t < soup.numTris(); ++t)
+                if (soup.triMtl[t] >= 0)
+                    tris[first + t].mat = nameToMat[soup.triMtl[t]];
+        }
     }
     const mrx_geometry &g = cfg.geo;
     for (uint32_t m = 0; m < g.num_meshes; ++m) {   // mgr.cpp:214-272
@@ -223,6 +248,40 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         texels.resize(texels.size() + n);
         std::memcpy(texels.data() + d.offset, img.rgba.data(), n * 4);
     }
+    // combined material table: API materials, then file materials whose map_Kd
+    // textures (PNG only; anything unreadable means untextured) follow the API textures
+    std::vector<mrx_material> allMats(cfg.materials, cfg.materials + cfg.num_materials);
+    for (const FileMat &fm : fileMats) {
+        mrx_material m {};
+        m.color[0] = fm.kd[0]; m.color[1] = fm.kd[1]; m.color[2] = fm.kd[2]; m.color[3] = 1.0f;
+        m.texture_idx = -1;
+        m.roughness = 0.8f;
+        m.metalness = 0.2f;
+        if (!fm.mapKd.empty()) {
+            int32_t found = -1;
+            for (size_t i = 0; i < fileTexPaths.size(); ++i)
+                if (fileTexPaths[i] == fm.mapKd)
+                    found = (int32_t)(cfg.num_textures + i);
+            if (found < 0) {
+                Image img;
+                std::string terr;
+                if (decodePNG(fm.mapKd, img, terr)) {
+                    TexDesc d {};
+                    d.offset = (uint32_t)texels.size();
+                    d.width = img.width;
+                    d.height = img.height;
+                    texDescs.push_back(d);
+                    const size_t n = (size_t)img.width * img.height;
+                    texels.resize(texels.size() + n);
+                    std::memcpy(texels.data() + d.offset, img.rgba.data(), n * 4);
+                    found = (int32_t)(cfg.num_textures + fileTexPaths.size());
+                    fileTexPaths.push_back(fm.mapKd);
+                }
+            }
+            m.texture_idx = found;
+        }
+        allMats.push_back(m);
+    }
     // resolve every object triangle's material once: mesh material if it
     // exists, else the default colour (white, untextured); a texture index
     // with no texture behind it means untextured
@@ -232,9 +291,9 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         tm.color[0] = tm.color[1] = tm.color[2] = tm.color[3] = 1.0f;
         tm.tex = -1;
         const int32_t m = tris[t].mat;
-        if (m >= 0 && (uint32_t)m < cfg.num_materials) {
-            std::memcpy(tm.color, cfg.materials[m].color, 16);
-            tm.tex = cfg.materials[m].texture_idx;
+        if (m >= 0 && (size_t)m < allMats.size()) {
+            std::memcpy(tm.color, allMats[m].color, 16);
+            tm.tex = allMats[m].texture_idx;
         }
         if (tm.tex < 0 || (uint32_t)tm.tex >= (uint32_t)texDescs.size())
             tm.tex = -1;
@@ -438,7 +497,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     inf.num_instances = (uint32_t)instObj.size();
     inf.num_objects = (uint32_t)r.objFirst.size();
     inf.num_triangles = (uint32_t)tris.size();
-    inf.num_materials = cfg.num_materials;
+    inf.num_materials = (uint32_t)allMats.size();
     inf.num_textures = (uint32_t)texDescs.size();
     inf.max_world_triangles = maxWorldTris;
     inf.storage_fast = nfast;

@@ -98,16 +98,28 @@ def lib():
 # --------------------------------------------------------------------------
 # independent asset readers
 # --------------------------------------------------------------------------
-def parse_obj(path):
+def parse_obj(path, with_materials=False):
     """Wavefront OBJ -> (tri_pos [T,3,3] f32, tri_uv [T,3,2] f32).
 
-    One object per file; polygons fan-triangulated; ``vt`` optional."""
+    One object per file; polygons fan-triangulated; ``vt`` optional.  With
+    ``with_materials`` also returns (tri_mtl [T] index into names or -1, names,
+    mtllib paths resolved against the OBJ's directory)."""
     vs, vts, tris_p, tris_t = [], [], [], []
+    tri_mtl, names, libs, cur = [], [], [], -1
+    base = os.path.dirname(path)
     with open(path, "r") as f:
         for line in f:
             parts = line.split()
             if not parts:
                 continue
+            if parts[0] == "usemtl" and len(parts) > 1:
+                name = line.split(None, 1)[1].strip()
+                if name not in names:
+                    names.append(name)
+                cur = names.index(name)
+            elif parts[0] == "mtllib" and len(parts) > 1:
+                name = line.split(None, 1)[1].strip()
+                libs.append(name if os.path.isabs(name) else os.path.join(base, name))
             if parts[0] == "v":
                 vs.append([float(x) for x in parts[1:4]])
             elif parts[0] == "vt":
@@ -128,9 +140,35 @@ def parse_obj(path):
                     tris_p.append([vs[c[0]] for c in tri])
                     tris_t.append([vts[c[1]] if c[1] is not None else [0.0, 0.0]
                                    for c in tri])
+                    tri_mtl.append(cur)
     pos = np.asarray(tris_p, dtype=np.float64).astype(np.float32).reshape(-1, 3, 3)
     uv = np.asarray(tris_t, dtype=np.float64).astype(np.float32).reshape(-1, 3, 2)
+    if with_materials:
+        return pos, uv, np.asarray(tri_mtl, dtype=np.int32), names, libs
     return pos, uv
+
+
+def parse_mtl(path):
+    """Wavefront MTL -> [(name, Kd rgb as float32, map_Kd path or None)]."""
+    out = []
+    base = os.path.dirname(path)
+    try:
+        f = open(path, "r")
+    except OSError:
+        return out
+    with f:
+        for line in f:
+            parts = line.split()
+            if not parts:
+                continue
+            if parts[0] == "newmtl" and len(parts) > 1:
+                out.append([line.split(None, 1)[1].strip(), [1.0, 1.0, 1.0], None])
+            elif out and parts[0] == "Kd" and len(parts) >= 4:
+                out[-1][1] = [float(np.float32(float(x))) for x in parts[1:4]]
+            elif out and parts[0] == "map_Kd" and len(parts) > 1:
+                name = parts[-1]
+                out[-1][2] = name if os.path.isabs(name) else os.path.join(base, name)
+    return [tuple(m) for m in out]
 
 
 def closed_orientation(tri_pos):
@@ -223,13 +261,30 @@ class FlatScene:
         # -- objects: disk assets first, then one object per raw mesh
         pos_l, uv_l, mat_l, first, count = [], [], [], [], []
         ntri = 0
+        mats = list(desc.materials)
+        file_mats = []              # (Kd, map_Kd) appended after the API materials
         for path, mat_id in desc.asset_paths:
-            p, t = parse_obj(_path(path))
+            p, t, tri_mtl, names, libs = parse_obj(_path(path), with_materials=True)
             pos_l.append(p)
             uv_l.append(t)
-            # intended semantics of the disabled block mgr.cpp:339-349:
-            # mat_id indexes the additional materials (no disk materials).
-            mat_l.append(np.full(len(p), int(mat_id), dtype=np.int32))
+            # intended semantics of the disabled block mgr.cpp:339-349: mat_id
+            # indexes the additional materials; with -1 a face keeps the
+            # material its OBJ names through mtllib / usemtl
+            tm = np.full(len(p), int(mat_id), dtype=np.int32)
+            if int(mat_id) < 0 and names:
+                lib = [m for ml in libs for m in parse_mtl(ml)]
+                name_to_mat = []
+                for n in names:
+                    hit = next((m for m in lib if m[0] == n), None)
+                    if hit is None:
+                        name_to_mat.append(-1)
+                    else:
+                        name_to_mat.append(len(mats) + len(file_mats))
+                        file_mats.append((hit[1], hit[2]))
+                for i, k in enumerate(tri_mtl):
+                    if k >= 0:
+                        tm[i] = name_to_mat[k]
+            mat_l.append(tm)
             first.append(ntri)
             count.append(len(p))
             ntri += len(p)
@@ -271,20 +326,40 @@ class FlatScene:
         self.obj_bbmin = np.asarray(bmin, dtype=np.float32).reshape(-1, 3)
         self.obj_bbmax = np.asarray(bmax, dtype=np.float32).reshape(-1, 3)
 
-        # -- materials / textures
-        mats = list(desc.materials)
-        self.mat_color = np.asarray([m[0] for m in mats],
-                                    dtype=np.float32).reshape(-1, 4)
-        self.mat_tex = np.asarray([m[1] for m in mats], dtype=np.int32)
+        # -- materials / textures (API ones first, then the files' own)
         texels, offs, tw, th = [], [], [], []
         o = 0
-        for p in desc.texture_paths:
-            img = decode_image(_path(p))
+
+        def add_texture(img):
+            nonlocal o
             offs.append(o)
             th.append(img.shape[0])
             tw.append(img.shape[1])
             texels.append(img.reshape(-1, 4))
             o += img.shape[0] * img.shape[1]
+
+        for p in desc.texture_paths:
+            add_texture(decode_image(_path(p)))
+        mat_color = [list(m[0]) for m in mats]
+        mat_tex = [int(m[1]) for m in mats]
+        file_tex = {}
+        for kd, map_kd in file_mats:
+            tex = -1
+            if map_kd:
+                if map_kd not in file_tex:
+                    try:
+                        if not map_kd.lower().endswith(".png"):
+                            raise OSError("only PNG textures are read")
+                        img = decode_image(map_kd)
+                        file_tex[map_kd] = len(texels)
+                        add_texture(img)
+                    except OSError:
+                        file_tex[map_kd] = -1
+                tex = file_tex[map_kd]
+            mat_color.append([kd[0], kd[1], kd[2], 1.0])
+            mat_tex.append(tex)
+        self.mat_color = np.asarray(mat_color, dtype=np.float32).reshape(-1, 4)
+        self.mat_tex = np.asarray(mat_tex, dtype=np.int32)
         self.tex_data = np.ascontiguousarray(
             np.concatenate(texels) if texels else np.zeros((1, 4)), np.uint8)
         self.tex_offset = np.asarray(offs if offs else [0], dtype=np.int64)

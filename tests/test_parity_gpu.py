@@ -206,6 +206,47 @@ def test_back_face_culling_cases(native):
     assert (got["tri_id"][1] >= 0).all()        # eye inside the cube: walls everywhere
 
 
+def test_obj_materials_from_mtl(native, tmp_path):
+    # mat_id -1: faces keep the materials their OBJ names (mtllib / usemtl):
+    # Kd colour, map_Kd PNG texture; unknown names, a missing library and an
+    # unreadable texture all fall back to the defaults
+    import shutil
+    shutil.copy(os.path.join(scenes.DATA_DIR, "cube.png"), tmp_path / "tex.png")
+    (tmp_path / "two.mtl").write_text(
+        "newmtl red\nKd 0.9 0.2 0.1\n"
+        "newmtl skin\nKd 0.8 0.8 1.0\nmap_Kd tex.png\n"
+        "newmtl broken\nKd 0.3 0.9 0.3\nmap_Kd missing.png\n")
+    (tmp_path / "quad.obj").write_text(
+        "mtllib two.mtl\nmtllib nowhere.mtl\n"
+        "v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv 3 0 -1\nv 3 0 1\nv 5 0 -1\nv 5 0 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "f 1/1 2/2 3/3\n"                       # no usemtl yet: default material
+        "usemtl skin\nf 1/1 3/3 4/4\n"
+        "usemtl red\nf 2/1 5/2 6/3\n"
+        "usemtl ghost\nf 2/1 6/3 3/4\n"        # not in any library
+        "usemtl broken\nf 5/1 7/2 8/3\n"
+        "usemtl skin\nf 5/1 8/3 6/4\n")
+    cams = [((2.0, -6.0, 0.0), IDENT), ((2.0, 6.0, 0.5), (0.0, 0.0, 0.0, 1.0))]
+    d = scenes.SceneDesc(
+        num_worlds=1, width=96, height=64,
+        asset_paths=[(str(tmp_path / "quad.obj"), -1), (CUBE, -1), (str(tmp_path / "quad.obj"), 0)],
+        materials=[((0.2, 0.4, 0.9, 1.0), -1, 0.5, 0.5)],
+        instances=[((0.0, 0.0, 0.0), IDENT, (1.0, 1.0, 1.0), 0),
+                   ((0.0, -2.0, 1.5), IDENT, (1.0, 1.0, 1.0), 1),
+                   ((0.0, 0.0, -2.2), IDENT, (1.0, 1.0, 1.0), 2)],
+        cameras=cams, worlds=[(3, 0, 2, 0)])
+    r, got, ref = _parity(d)
+    from oracle import oracle
+    fs = oracle.FlatScene(d)
+    # API material 0, then quad.obj's skin / red / broken in order of first use
+    # ("ghost" is in no library), then cube.obj's cube
+    assert fs.mat_tex.tolist() == [-1, 0, -1, -1, 1]
+    assert fs.tri_mat[:6].tolist() == [-1, 1, 2, -1, 3, 1]
+    assert set(fs.tri_mat[6:18].tolist()) == {4} and set(fs.tri_mat[18:].tolist()) == {0}
+    colours = {tuple(c) for c in got["rgb"][0].reshape(-1, 4).tolist()}
+    assert len(colours) > 10                      # textured faces show many texel colours
+
+
 def test_zero_worlds_and_zero_views(native):
     d = scenes.synthetic_scene(2)
     d.worlds = []
@@ -333,6 +374,15 @@ def test_raw_c_abi_through_ctypes(native):
                                   oc.ctypes.data_as(ctypes.c_void_p)) == 0
     assert np.array_equal(tp.reshape(-1, 3, 3), fs.tri_pos) and np.array_equal(tu.reshape(-1, 3, 2), fs.tri_uv)
     assert np.array_equal(tm, fs.tri_mat) and np.array_equal(of, fs.obj_first_tri)
+    # the same cross-check with file materials in play (cube.obj -> cube.mtl)
+    d2 = scenes.synthetic_scene(2)
+    d2.asset_paths = [(d2.asset_paths[0][0], -1), d2.asset_paths[1]]
+    r2 = make_product(d2)
+    fs2 = oracle.FlatScene(d2)
+    tm2 = np.empty(len(fs2.tri_mat), np.int32)
+    assert lib.mrx_copy_triangles(ctypes.c_void_p(r2.native_handle()), None, None,
+                                  tm2.ctypes.data_as(ctypes.c_void_p), None, None) == 0
+    assert np.array_equal(tm2, fs2.tri_mat) and tm2[0] == len(d2.materials)
     ms = ctypes.c_float()
     assert lib.mrx_time_renders(h, 5, ctypes.byref(ms)) == 0 and ms.value > 0
     lib.mrx_destroy(h)
