@@ -198,6 +198,11 @@ int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv,
                  uint32_t *num_tris);
 int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width,
                    uint32_t *height);
+/*    What the OBJ reader makes of a file's material statements, as JSON text:
+ *    {"num_tris":N,"tri_mtl":[...],"names":[...],"libs":[...],
+ *     "materials":[{"name":..,"kd":[r,g,b],"map_kd":..},...]} (materials = every
+ *    newmtl of the file's mtllibs).  Returns the length, or a negative MRX_E_*. */
+int64_t mrx_describe_obj_materials(const char *path, char *json, uint64_t capacity);
 void mrx_free(void *p);
 
 int mrx_device_count(void);

@@ -810,6 +810,50 @@ int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width, uint32_t *
     return MRX_OK;
 }
 
+int64_t mrx_describe_obj_materials(const char *path, char *json, uint64_t capacity)
+{
+    if (!path || !json)
+        return fail(MRX_E_INVALID, "null argument");
+    mrx::TriSoup soup;
+    std::string err;
+    if (!mrx::loadOBJ(path, soup, err))
+        return fail(MRX_E_ASSET, err);
+    auto quote = [](const std::string &s) {
+        std::string o = "\"";
+        for (char c : s) {
+            if (c == '"' || c == '\\') o += '\\';
+            o += c;
+        }
+        return o + "\"";
+    };
+    std::string out = "{\"num_tris\":" + std::to_string(soup.numTris()) + ",\"tri_mtl\":[";
+    for (size_t i = 0; i < soup.triMtl.size(); ++i)
+        out += (i ? "," : "") + std::to_string(soup.triMtl[i]);
+    out += "],\"names\":[";
+    for (size_t i = 0; i < soup.mtlNames.size(); ++i)
+        out += (i ? "," : "") + quote(soup.mtlNames[i]);
+    out += "],\"libs\":[";
+    for (size_t i = 0; i < soup.mtlLibs.size(); ++i)
+        out += (i ? "," : "") + quote(soup.mtlLibs[i]);
+    out += "],\"materials\":[";
+    std::vector<mrx::MtlMaterial> lib;
+    for (const std::string &ml : soup.mtlLibs) {
+        std::string merr;
+        (void)mrx::loadMTL(ml, lib, merr);
+    }
+    for (size_t i = 0; i < lib.size(); ++i) {
+        char kd[96];
+        std::snprintf(kd, sizeof kd, "[%.9g,%.9g,%.9g]", lib[i].kd[0], lib[i].kd[1], lib[i].kd[2]);
+        out += std::string(i ? "," : "") + "{\"name\":" + quote(lib[i].name) + ",\"kd\":" + kd +
+               ",\"map_kd\":" + quote(lib[i].mapKd) + "}";
+    }
+    out += "]}";
+    if (out.size() + 1 > capacity)
+        return fail(MRX_E_INVALID, "buffer too small");
+    std::memcpy(json, out.c_str(), out.size() + 1);
+    return (int64_t)out.size();
+}
+
 void mrx_free(void *p) { std::free(p); }
 
 }  // extern "C"

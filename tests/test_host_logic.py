@@ -105,6 +105,33 @@ def test_obj_reader_polygons_negative_indices_missing_uv(native, oracle_mod, tmp
     assert np.all(uv[2:] == 0)
 
 
+def test_obj_material_statements_match_independent_parser(native, oracle_mod, tmp_path):
+    import json
+    lib = native.load_capi()
+    lib.mrx_describe_obj_materials.restype = ctypes.c_int64
+    (tmp_path / "a.mtl").write_text("# comment\nnewmtl one\nKd 0.25 0.5 0.75\nmap_Kd -s 1 1 1 tex/one.png\n"
+                                    "newmtl two words\nKd 1 0 0\n")
+    (tmp_path / "m.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\n"
+                                    "f 1 2 3\nusemtl two words\nf 2 4 3\nusemtl one\nf 1 2 4 3\n"
+                                    "usemtl two words\nf 1 4 3\n")
+    for path in (str(tmp_path / "m.obj"), os.path.join(scenes.DATA_DIR, "cube.obj"),
+                 os.path.join(scenes.DATA_DIR, "plane.obj")):
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = lib.mrx_describe_obj_materials(path.encode(), buf, ctypes.c_uint64(len(buf)))
+        assert n > 0
+        got = json.loads(buf.value.decode())
+        pos, uv, tri_mtl, names, libs = oracle_mod.parse_obj(path, with_materials=True)
+        assert got["num_tris"] == len(pos)
+        assert got["tri_mtl"] == tri_mtl.tolist() and got["names"] == names and got["libs"] == libs
+        ref = [m for ml in libs for m in oracle_mod.parse_mtl(ml)]
+        assert [m["name"] for m in got["materials"]] == [m[0] for m in ref]
+        for g, r in zip(got["materials"], ref):
+            assert np.array_equal(np.float32(g["kd"]), np.float32(r[1]))
+            assert g["map_kd"] == (r[2] or "")
+    # cube.obj names cube.mtl -> Kd 0.588, map_Kd cube.png (data/cube.mtl:7,13)
+    assert got is not None
+
+
 def test_obj_reader_errors(native, tmp_path):
     lib = native.load_capi()
     lib.mrx_last_error.restype = ctypes.c_char_p
