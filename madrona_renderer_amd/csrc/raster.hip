@@ -43,10 +43,11 @@ struct WaveLdsCompact {
     float cold[kChunk][kCold];   // u/v planes, lit colour
 };
 
+// S2: every 3-term dot product is one rounded product and two fused steps
 __device__ __forceinline__ float dot3(float ax, float ay, float az,
                                       float bx, float by, float bz)
 {
-    return (ax * bx + ay * by) + az * bz;
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
 }
 
 // S1
@@ -72,7 +73,7 @@ __device__ __forceinline__ void cross3(const float a[3], const float b[3], float
 __device__ __forceinline__ uint32_t toU8(float c)
 {
     c = fminf(fmaxf(c, 0.0f), 1.0f);
-    return (uint32_t)(c * 255.0f + 0.5f);
+    return (uint32_t)__builtin_fmaf(c, 255.0f, 0.5f);
 }
 
 struct ViewConst {
@@ -156,8 +157,9 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            P[j][r] = dot3(MV[r][0], MV[r][1], MV[r][2],
-                           op[3 * j], op[3 * j + 1], op[3 * j + 2]) + tv[r];
+            P[j][r] = __builtin_fmaf(MV[r][2], op[3 * j + 2],
+                                     __builtin_fmaf(MV[r][1], op[3 * j + 1],
+                                                    __builtin_fmaf(MV[r][0], op[3 * j], tv[r])));
 
     float N[3][3], e1[3], e2[3], nn[3];
     cross3(P[1], P[2], N[0]);
@@ -208,7 +210,7 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     for (int e = 0; e < 3; ++e) {
         const float ax = N[e][0] * p.sx;
         const float az = N[e][2] * p.sz;
-        const float cc = (N[e][0] * p.ox + N[e][1]) + N[e][2] * p.oz;
+        const float cc = __builtin_fmaf(N[e][2], p.oz, __builtin_fmaf(N[e][0], p.ox, N[e][1]));
         A[e] = (tr ? az : ax) * flip;
         B[e] = (tr ? ax : az) * flip;
         C[e] = cc * flip;
@@ -222,17 +224,17 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
         const float az = (nn[2] * p.sz) * rd;
         out.Dx = tr ? az : ax;
         out.Dy = tr ? ax : az;
-        out.Dc = ((nn[0] * p.ox + nn[1]) + nn[2] * p.oz) * rd;
+        out.Dc = __builtin_fmaf(nn[2], p.oz, __builtin_fmaf(nn[0], p.ox, nn[1])) * rd;
     }
     // u/v planes (S8) are only ever read for textured triangles
     if (tex >= 0) {
         const float rad = fabsf(rd);
-        cold[0] = ((uv[0] * A[0] + uv[2] * A[1]) + uv[4] * A[2]) * rad;
-        cold[1] = ((uv[0] * B[0] + uv[2] * B[1]) + uv[4] * B[2]) * rad;
-        cold[2] = ((uv[0] * C[0] + uv[2] * C[1]) + uv[4] * C[2]) * rad;
-        cold[3] = ((uv[1] * A[0] + uv[3] * A[1]) + uv[5] * A[2]) * rad;
-        cold[4] = ((uv[1] * B[0] + uv[3] * B[1]) + uv[5] * B[2]) * rad;
-        cold[5] = ((uv[1] * C[0] + uv[3] * C[1]) + uv[5] * C[2]) * rad;
+        cold[0] = __builtin_fmaf(uv[4], A[2], __builtin_fmaf(uv[2], A[1], uv[0] * A[0])) * rad;
+        cold[1] = __builtin_fmaf(uv[4], B[2], __builtin_fmaf(uv[2], B[1], uv[0] * B[0])) * rad;
+        cold[2] = __builtin_fmaf(uv[4], C[2], __builtin_fmaf(uv[2], C[1], uv[0] * C[0])) * rad;
+        cold[3] = __builtin_fmaf(uv[5], A[2], __builtin_fmaf(uv[3], A[1], uv[1] * A[0])) * rad;
+        cold[4] = __builtin_fmaf(uv[5], B[2], __builtin_fmaf(uv[3], B[1], uv[1] * B[0])) * rad;
+        cold[5] = __builtin_fmaf(uv[5], C[2], __builtin_fmaf(uv[3], C[1], uv[1] * C[0])) * rad;
     }
 
     // S7: flat two-sided Lambert
@@ -240,7 +242,7 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     float ndl = dot3(nn[0], nn[1], nn[2], vc.lv[0], vc.lv[1], vc.lv[2]) / len;
     if (d > 0.0f)
         ndl = -ndl;
-    const float lit = p.ambient + p.diffuse * fmaxf(ndl, 0.0f);
+    const float lit = __builtin_fmaf(p.diffuse, fmaxf(ndl, 0.0f), p.ambient);
     const float l0 = lit * mc.x, l1 = lit * mc.y, l2 = lit * mc.z;
     cold[6] = l0; cold[7] = l1; cold[8] = l2;
     const uint32_t rgba = toU8(l0) | (toU8(l1) << 8) | (toU8(l2) << 16) | 0xFF000000u;

@@ -105,10 +105,11 @@ static void quat_to_mat(const float q[4], float R[3][3])
     R[2][0] = xz - wy;          R[2][1] = yz + wx;          R[2][2] = 1.0f - (xx + yy);
 }
 
+/* S2: every 3-term dot product is one rounded product and two fused steps */
 static inline float dot3(float ax, float ay, float az,
                          float bx, float by, float bz)
 {
-    return (ax * bx + ay * by) + az * bz;
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
 
 static inline void cross3(const float a[3], const float b[3], float o[3])
@@ -121,7 +122,7 @@ static inline void cross3(const float a[3], const float b[3], float o[3])
 static inline uint32_t to_u8(float c)
 {
     c = fminf(fmaxf(c, 0.0f), 1.0f);
-    return (uint32_t)(c * 255.0f + 0.5f);
+    return (uint32_t)fmaf(c, 255.0f, 0.5f);
 }
 
 /* S3-S8: set up every triangle of the world of view v.  Returns the count of
@@ -182,8 +183,9 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
             float P[3][3];
             for (int j = 0; j < 3; ++j)
                 for (int r = 0; r < 3; ++r)
-                    P[j][r] = dot3(MV[r][0], MV[r][1], MV[r][2],
-                                   op[3 * j], op[3 * j + 1], op[3 * j + 2]) + tv[r];
+                    P[j][r] = fmaf(MV[r][2], op[3 * j + 2],
+                                   fmaf(MV[r][1], op[3 * j + 1],
+                                        fmaf(MV[r][0], op[3 * j], tv[r])));
             float N[3][3], e1[3], e2[3], nn[3];
             cross3(P[1], P[2], N[0]);
             cross3(P[2], P[0], N[1]);
@@ -203,7 +205,7 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
             for (int e = 0; e < 3; ++e) {
                 float ax = N[e][0] * s->sx;
                 float az = N[e][2] * s->sz;
-                float cc = (N[e][0] * s->ox + N[e][1]) + N[e][2] * s->oz;
+                float cc = fmaf(N[e][2], s->oz, fmaf(N[e][0], s->ox, N[e][1]));
                 o->A[e] = (s->transposed ? az : ax) * flip;
                 o->B[e] = (s->transposed ? ax : az) * flip;
                 o->C[e] = cc * flip;
@@ -214,21 +216,21 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
                 float az = (nn[2] * s->sz) * rd;
                 o->Dx = s->transposed ? az : ax;
                 o->Dy = s->transposed ? ax : az;
-                o->Dc = ((nn[0] * s->ox + nn[1]) + nn[2] * s->oz) * rd;
+                o->Dc = fmaf(nn[2], s->oz, fmaf(nn[0], s->ox, nn[1])) * rd;
             }
             const float rad = fabsf(rd);
-            o->Ua = ((uv[0] * o->A[0] + uv[2] * o->A[1]) + uv[4] * o->A[2]) * rad;
-            o->Ub = ((uv[0] * o->B[0] + uv[2] * o->B[1]) + uv[4] * o->B[2]) * rad;
-            o->Uc = ((uv[0] * o->C[0] + uv[2] * o->C[1]) + uv[4] * o->C[2]) * rad;
-            o->Va = ((uv[1] * o->A[0] + uv[3] * o->A[1]) + uv[5] * o->A[2]) * rad;
-            o->Vb = ((uv[1] * o->B[0] + uv[3] * o->B[1]) + uv[5] * o->B[2]) * rad;
-            o->Vc = ((uv[1] * o->C[0] + uv[3] * o->C[1]) + uv[5] * o->C[2]) * rad;
+            o->Ua = fmaf(uv[4], o->A[2], fmaf(uv[2], o->A[1], uv[0] * o->A[0])) * rad;
+            o->Ub = fmaf(uv[4], o->B[2], fmaf(uv[2], o->B[1], uv[0] * o->B[0])) * rad;
+            o->Uc = fmaf(uv[4], o->C[2], fmaf(uv[2], o->C[1], uv[0] * o->C[0])) * rad;
+            o->Va = fmaf(uv[5], o->A[2], fmaf(uv[3], o->A[1], uv[1] * o->A[0])) * rad;
+            o->Vb = fmaf(uv[5], o->B[2], fmaf(uv[3], o->B[1], uv[1] * o->B[0])) * rad;
+            o->Vc = fmaf(uv[5], o->C[2], fmaf(uv[3], o->C[1], uv[1] * o->C[0])) * rad;
             /* S7: flat two-sided Lambert */
             const float len = sqrtf(dot3(nn[0], nn[1], nn[2], nn[0], nn[1], nn[2]));
             float ndl = dot3(nn[0], nn[1], nn[2], lv[0], lv[1], lv[2]) / len;
             if (d > 0.0f)
                 ndl = -ndl;
-            const float lit = s->ambient + s->diffuse * fmaxf(ndl, 0.0f);
+            const float lit = fmaf(s->diffuse, fmaxf(ndl, 0.0f), s->ambient);
             const int m = s->tri_mat[ti];
             const float *col = (m >= 0 && m < s->num_materials)
                                    ? &s->mat_color[4 * m] : s->default_color;
