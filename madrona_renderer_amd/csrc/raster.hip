@@ -1126,6 +1126,9 @@ void rasterGroupKernel(const RasterParams p)
     }
     MRX_STAMP(5);
     MRX_STAMP(6);
+    if (stamps && lane == 0)       // where this wave ran: HW_ID (reg 4) and XCC_ID (reg 20)
+        stamps[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                    (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #undef MRX_STAMP
 }
 

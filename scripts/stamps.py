@@ -28,3 +28,22 @@ life = us[:, :, 6] - us[:, :, 0]
 print("wave lifetime   p50 %.2f  max %.2f" % (np.median(life), life.max()))
 print("S phase (wave0) p50 %.2f" % np.median(us[:, 0, 3] - us[:, 0, 0]))
 print("barrier->exit   p50 %.2f" % np.median(us[:, :, 6] - us[:, :, 4]))
+
+# where did the spread come from?  group exits by XCC and by CU
+hw = st[st[:, 0, 0] > 0][:, 0, 7]
+xcc = (hw >> 32) & 0xF
+cu = (hw >> 8) & 0xF
+se = (hw >> 13) & 0x7
+sh = (hw >> 12) & 0x1
+ex = us[:, :, 6].max(axis=1)
+print("exit by XCC:", " ".join(f"{x}:{ex[xcc == x].mean():.1f}/{ex[xcc == x].max():.1f}" for x in sorted(set(xcc.tolist()))))
+key = xcc * 1000 + se * 100 + sh * 16 + cu
+import collections
+per_cu = collections.defaultdict(list)
+for k, e in zip(key.tolist(), ex.tolist()):
+    per_cu[k].append(e)
+within = np.mean([max(v) - min(v) for v in per_cu.values() if len(v) > 1])
+cu_last = np.array([max(v) for v in per_cu.values()])
+print(f"distinct CUs seen {len(per_cu)}; WGs per CU {np.mean([len(v) for v in per_cu.values()]):.2f}; "
+      f"mean spread of exits within a CU {within:.2f} us; per-CU last exit: min {cu_last.min():.1f} "
+      f"p50 {np.median(cu_last):.1f} max {cu_last.max():.1f}")
