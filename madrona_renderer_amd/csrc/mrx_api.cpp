@@ -487,6 +487,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             MRX_HIP(hipMemset(r.stamps.ptr, 0, n * sizeof(unsigned long long)));
             p.debugStamps = r.stamps.ptr;
         }
+    p.xcdSkew = 0;
+    p.xcdSkewWanted = -1;
+    if (const char *dbg = std::getenv("MRX_XCD_SKEW"))
+        p.xcdSkewWanted = std::atoi(dbg);
     p.debugSlots = 0;
     if (const char *dbg = std::getenv("MRX_DEBUG_SLOTS"))
         p.debugSlots = std::atoi(dbg);

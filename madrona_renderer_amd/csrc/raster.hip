@@ -630,7 +630,7 @@ __device__ __forceinline__ void pixelTest(const PlanePairs &q, f32x2 r01, f32x2 
 // k of the chunk survives classification for this region), in triangle order.
 // Triangle planes are broadcast from LDS (all lanes read the same 48 bytes).
 template <bool NEAR, int IDSHIFT>
-__device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t act,
+__device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t act, int recBase,
                                              const float (&px)[kRegionBlocks], float py,
                                              float invNear,
                                              float (&best)[kRegionBlocks],
@@ -638,7 +638,7 @@ __device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t
 {
     const f32x2 yy = { py, py };
     for (; act != 0; act &= act - 1) {
-        const int k = __builtin_ctzll(act);      // record index in the LDS tables
+        const int k = recBase + __builtin_ctzll(act);   // record index in the LDS tables
         const PlanePairs q = loadPlanes(planes, k);
         const f32x2 r01 = fma2(q.B01, yy, q.C01);
         const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
@@ -648,6 +648,25 @@ __device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t
         for (int b = 0; b < kRegionBlocks; ++b)
             pixelTest<NEAR>(q, r01, r2d, px[b], invNear, k << IDSHIFT, best[b], bid[b]);
     }
+}
+
+// Output stores are write-through (agent scope, `sc1`): the images are written
+// once and never read back by this kernel, and lines left dirty in the XCDs'
+// L2s would have to be written back at the end of the kernel, where nothing
+// overlaps it (scripts/micro/store_modes.hip: 3.1 us -> 0.9 us between
+// back-to-back 128 MiB launches).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void streamStore16(void *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const u32x4 v = { a, b, c, d };
+    // s_nop 1: on gfx940+ a VALU write to the data registers of a >64-bit store
+    // needs two wait states after it; the compiler cannot see into the asm to
+    // insert them (one is not enough: dword 2 of the data was overwritten)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void streamStore4(void *dst, uint32_t a)
+{
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(dst), "v"(a) : "memory");
 }
 
 // Store a region whose pixels are already shaded (chunked kernel).  A lane owns
@@ -668,18 +687,19 @@ __device__ __forceinline__ void outputRegion(const RasterParams &p, const TileCt
         return;
     const size_t o = ((size_t)t.view * p.nslow + fy) * p.nfast + fx0;
     if ((p.nfast & 3u) == 0 && fx0 + 3 < p.nfast) {
-        *reinterpret_cast<uint4 *>(p.rgb + o) = make_uint4(rgba[0], rgba[1], rgba[2], rgba[3]);
-        *reinterpret_cast<float4 *>(p.depth + o) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        streamStore16(p.rgb + o, rgba[0], rgba[1], rgba[2], rgba[3]);
+        streamStore16(p.depth + o, __float_as_uint(dep[0]), __float_as_uint(dep[1]),
+                      __float_as_uint(dep[2]), __float_as_uint(dep[3]));
         if (IDS)
-            *reinterpret_cast<int4 *>(p.ids + o) = make_int4(id[0], id[1], id[2], id[3]);
+            streamStore16(p.ids + o, (uint32_t)id[0], (uint32_t)id[1], (uint32_t)id[2], (uint32_t)id[3]);
     } else {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             if (fx0 + b < p.nfast) {
-                p.rgb[o + b] = rgba[b];
-                p.depth[o + b] = dep[b];
+                streamStore4(p.rgb + o + b, rgba[b]);
+                streamStore4(p.depth + o + b, __float_as_uint(dep[b]));
                 if (IDS)
-                    p.ids[o + b] = id[b];
+                    streamStore4(p.ids + o + b, (uint32_t)id[b]);
             }
         }
     }
@@ -757,7 +777,7 @@ void rasterChunkedKernel(const RasterParams p)
                 px[b] = (float)(fx0 + b);
             const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
             if (!(p.debugSkip & 2u))
-                rasterRegion<true, 0>(lds.planes, act, px, py, invNear, best[g], bid[g]);
+                rasterRegion<true, 0>(lds.planes, act, 0, px, py, invNear, best[g], bid[g]);
             // shade this chunk's winners before its records are replaced
 #pragma unroll
             for (int b = 0; b < kRegionBlocks; ++b) {
@@ -789,14 +809,18 @@ void rasterChunkedKernel(const RasterParams p)
 //   R+O all waves pull (tile, strip) items off an LDS counter, rasterise the
 //       strip's two regions and store them.
 // ---------------------------------------------------------------------------
-constexpr int kBackground = kChunk;   // record index of "nothing hit"
+// A group is normally kChunk records (G = kChunk / SLOTS tiles); with the
+// XCD-aware split a workgroup on a fast XCD carries one 16-slot tile more.
+constexpr int kGroupRecs = kChunk + 16;
+constexpr int kGroupTilesMax = 5;
+constexpr int kBackground = kGroupRecs;   // record index of "nothing hit"
 
 struct GroupLds {
-    float planes[kChunk][16];           // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | bbox
-    uint32_t masks[kChunk];             // region bits 0..15, near-free bits 16..19, live bit 31
-    float shade[kChunk + 1][4];         // rgba, texture, objectID, world-local index
-    float cold[kChunk][kCold];          // u/v planes, lit colour
-    uint32_t tileInfo[4][4];            // per tile of the group: view, x0, y0, flags
+    float planes[kGroupRecs][16];       // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | bbox
+    uint32_t masks[kGroupRecs];         // region bits 0..15, near-free bits 16..19, live bit 31
+    float shade[kGroupRecs + 1][4];     // rgba, texture, objectID, world-local index
+    float cold[kGroupRecs][kCold];      // u/v planes, lit colour
+    uint32_t tileInfo[kGroupTilesMax][4];   // per tile of the group: view, x0, y0, flags
     uint32_t nextItem;                  // (tile, strip) work counter of phase R
 };
 constexpr uint32_t kTileValid = 4u;
@@ -843,18 +867,19 @@ __device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLd
     if (p.debugSkip & 1u)
         return;
     if (FULL) {
-        *reinterpret_cast<uint4 *>(rgbTile + pixOff) = make_uint4(rgba[0], rgba[1], rgba[2], rgba[3]);
-        *reinterpret_cast<float4 *>(depthTile + pixOff) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        streamStore16(rgbTile + pixOff, rgba[0], rgba[1], rgba[2], rgba[3]);
+        streamStore16(depthTile + pixOff, __float_as_uint(dep[0]), __float_as_uint(dep[1]),
+                      __float_as_uint(dep[2]), __float_as_uint(dep[3]));
         if (IDS)
-            *reinterpret_cast<int4 *>(idsTile + pixOff) = make_int4(id[0], id[1], id[2], id[3]);
+            streamStore16(idsTile + pixOff, (uint32_t)id[0], (uint32_t)id[1], (uint32_t)id[2], (uint32_t)id[3]);
     } else if (fy < p.nslow) {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             if (fx0 + b < p.nfast) {
-                rgbTile[pixOff + b] = rgba[b];
-                depthTile[pixOff + b] = dep[b];
+                streamStore4(rgbTile + pixOff + b, rgba[b]);
+                streamStore4(depthTile + pixOff + b, __float_as_uint(dep[b]));
                 if (IDS)
-                    idsTile[pixOff + b] = id[b];
+                    streamStore4(idsTile + pixOff + b, (uint32_t)id[b]);
             }
         }
     }
@@ -870,18 +895,18 @@ __device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t 
         return;
     const uint32_t bg = 0xFF000000u;
     if (FULL) {
-        *reinterpret_cast<uint4 *>(rgbTile + pixOff) = make_uint4(bg, bg, bg, bg);
-        *reinterpret_cast<float4 *>(depthTile + pixOff) = make_float4(0.f, 0.f, 0.f, 0.f);
+        streamStore16(rgbTile + pixOff, bg, bg, bg, bg);
+        streamStore16(depthTile + pixOff, 0u, 0u, 0u, 0u);
         if (IDS)
-            *reinterpret_cast<int4 *>(idsTile + pixOff) = make_int4(-1, -1, -1, -1);
+            streamStore16(idsTile + pixOff, ~0u, ~0u, ~0u, ~0u);
     } else if (fy < p.nslow) {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             if (fx0 + b < p.nfast) {
-                rgbTile[pixOff + b] = bg;
-                depthTile[pixOff + b] = 0.0f;
+                streamStore4(rgbTile + pixOff + b, bg);
+                streamStore4(depthTile + pixOff + b, 0u);
                 if (IDS)
-                    idsTile[pixOff + b] = -1;
+                    streamStore4(idsTile + pixOff + b, ~0u);
             }
         }
     }
@@ -904,7 +929,22 @@ void rasterGroupKernel(const RasterParams p)
     const int lane = threadIdx.x % kWave;
     const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
     const uint32_t numItems = p.numViews * tilesPerView;
+    // XCD-aware split (see launchRaster): workgroup b runs on XCD b % 8 and
+    // the odd XCD of each pair drains its stores more slowly.  Workgroups 2m
+    // and 2m+1 share the tile between their two runs of four: the odd one
+    // leaves its first p.xcdSkew strips to the even one (both set the tile up).
     const uint32_t item0 = blockIdx.x * G;
+    uint32_t groupTiles = G, firstStrip = 0, numStrips = G * 8;
+    if (SLOTS == 16 && p.xcdSkew) {
+        if (blockIdx.x & 1u) {
+            firstStrip = p.xcdSkew;
+            numStrips -= p.xcdSkew;
+        } else {
+            groupTiles = G + 1;
+            numStrips += p.xcdSkew;
+        }
+    }
+    const int groupRecs = (int)groupTiles * SLOTS;
     const float invNear = p.invNear, invFar = p.invFar;
     if (p.debugSkip & 16u)
         return;                                   // timing aid: bare launch
@@ -917,11 +957,14 @@ void rasterGroupKernel(const RasterParams p)
     } while (0)
     MRX_STAMP(0);
 
-    // ---- S1: wave 0, lane = (tile j of the group, triangle slot k): setup
-    if (wave == 0) {
-        const int j = lane / SLOTS, k = lane % SLOTS;
+    // ---- S1: wave 0 (and wave 1 for a fifth tile), lane = (tile j of the
+    //      group, triangle slot k): setup
+    if (wave * kWave < groupRecs) {
+        const int rec = wave * kWave + lane;
+        const int j = rec / SLOTS, k = rec % SLOTS;
         const uint32_t item = item0 + j;
-        const bool tileOk = item < numItems;
+        const bool recOk = rec < groupRecs;
+        const bool tileOk = item < numItems && recOk;
         TileCtx t;
         // integer divisions cost ~25 VALU each: real (scalar) branches around
         // them for the common one-tile-per-view / one-camera-per-world cases
@@ -979,25 +1022,27 @@ void rasterGroupKernel(const RasterParams p)
         c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
         c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
         bool valid = false;
-        lds.shade[lane][1] = __int_as_float(-1);
         MRX_STAMP(1);
-        if ((uint32_t)k < t.numTris && !(p.debugSkip & 8u))
-            valid = setupTriangle(p, vc, wt, k, c, lds.shade[lane], lds.cold[lane]);
-        MRX_STAMP(2);
-        float4 *dst = reinterpret_cast<float4 *>(lds.planes[lane]);
-        dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
-        dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
-        dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
-        dst[3] = make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1);
-        // bit 31 marks a live triangle until classification replaces the word
-        lds.masks[lane] = (valid && !(p.debugSkip & 4u)) ? 0x80000000u : 0u;
-        if (k == 0) {
-            lds.tileInfo[j][0] = t.view;
-            lds.tileInfo[j][1] = t.tileX0;
-            lds.tileInfo[j][2] = t.tileY0;
-            lds.tileInfo[j][3] = tileOk ? kTileValid : 0u;
+        if (recOk) {
+            lds.shade[rec][1] = __int_as_float(-1);
+            if ((uint32_t)k < t.numTris && !(p.debugSkip & 8u))
+                valid = setupTriangle(p, vc, wt, k, c, lds.shade[rec], lds.cold[rec]);
+            MRX_STAMP(2);
+            float4 *dst = reinterpret_cast<float4 *>(lds.planes[rec]);
+            dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
+            dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
+            dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
+            dst[3] = make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1);
+            // bit 31 marks a live triangle until classification replaces the word
+            lds.masks[rec] = (valid && !(p.debugSkip & 4u)) ? 0x80000000u : 0u;
+            if (k == 0) {
+                lds.tileInfo[j][0] = t.view;
+                lds.tileInfo[j][1] = t.tileX0;
+                lds.tileInfo[j][2] = t.tileY0;
+                lds.tileInfo[j][3] = tileOk ? kTileValid : 0u;
+            }
         }
-        if (lane == 0) {
+        if (rec == 0) {
             lds.nextItem = 0;
             lds.shade[kBackground][0] = __uint_as_float(0xFF000000u);
             lds.shade[kBackground][1] = __int_as_float(-1);
@@ -1008,12 +1053,16 @@ void rasterGroupKernel(const RasterParams p)
     __syncthreads();
     MRX_STAMP(3);
 
-    // ---- S2: every wave classifies two strips (four 32x8 regions) of each triangle
-    //      (lane = the same (tile, slot) as in S1), results OR-ed in LDS:
-    //      bits 0..15 regions, bits 16..19 "near-free over this wave's strips"
-    {
-        const int j = lane / SLOTS;
-        const float4 *src = reinterpret_cast<const float4 *>(lds.planes[lane]);
+    // ---- S2: waves 0-3 each classify two strips (four 32x8 regions) of every
+    //      triangle (lane = the same (tile, slot) as in S1), results OR-ed in LDS:
+    //      bits 0..15 regions, bits 16..19 "near-free over this wave's strips".
+    //      A fifth tile's records go to waves 4-7, or to a second pass.
+    constexpr int kClassifyStride = (groupWaves(TEX) / 4) * kWave;
+    for (int rec = (wave >> 2) * kWave + lane; rec - lane < groupRecs; rec += kClassifyStride) {
+        if (rec >= groupRecs || !(lds.masks[rec] & 0x80000000u))
+            continue;
+        const int j = rec / SLOTS;
+        const float4 *src = reinterpret_cast<const float4 *>(lds.planes[rec]);
         const float4 a = src[0], b = src[1], cc = src[2], bb = src[3];
         TriPlanes c;
         c.A0 = a.x; c.A1 = a.y; c.A2 = a.z; c.Dx = a.w;
@@ -1021,20 +1070,18 @@ void rasterGroupKernel(const RasterParams p)
         c.C0 = cc.x; c.C1 = cc.y; c.C2 = cc.z; c.Dc = cc.w;
         c.bbX0 = bb.x; c.bbX1 = bb.y; c.bbY0 = bb.z; c.bbY1 = bb.w;
         const uint32_t tx0 = lds.tileInfo[j][1], ty0 = lds.tileInfo[j][2];
-        if (wave < 4 && (lds.masks[lane] & 0x80000000u)) {
-            bool nearOk = false;
-            uint32_t m;
-            switch (wave) {
-            case 0: m = classifyStrips<0, 2>(c, tx0, ty0, invNear, invFar, nearOk); break;
-            case 1: m = classifyStrips<2, 4>(c, tx0, ty0, invNear, invFar, nearOk); break;
-            case 2: m = classifyStrips<4, 6>(c, tx0, ty0, invNear, invFar, nearOk); break;
-            default: m = classifyStrips<6, 8>(c, tx0, ty0, invNear, invFar, nearOk); break;
-            }
-            if (nearOk)
-                m |= 1u << (16 + wave);
-            if (m)
-                atomicOr(&lds.masks[lane], m);
+        bool nearOk = false;
+        uint32_t m;
+        switch (wave & 3) {
+        case 0: m = classifyStrips<0, 2>(c, tx0, ty0, invNear, invFar, nearOk); break;
+        case 1: m = classifyStrips<2, 4>(c, tx0, ty0, invNear, invFar, nearOk); break;
+        case 2: m = classifyStrips<4, 6>(c, tx0, ty0, invNear, invFar, nearOk); break;
+        default: m = classifyStrips<6, 8>(c, tx0, ty0, invNear, invFar, nearOk); break;
         }
+        if (nearOk)
+            m |= 1u << (16 + (wave & 3));
+        if (m)
+            atomicOr(&lds.masks[rec], m);
     }
     __syncthreads();
     MRX_STAMP(4);
@@ -1058,8 +1105,9 @@ void rasterGroupKernel(const RasterParams p)
         if (lane == 0)
             item = atomicAdd(&lds.nextItem, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= (uint32_t)(G * 8))
+        if (item >= numStrips)
             break;
+        item += firstStrip;
         const int j = (int)(item >> 3), strip = (int)(item & 7u);
         if (j != cachedTile) {
             cachedTile = j;
@@ -1093,8 +1141,8 @@ void rasterGroupKernel(const RasterParams p)
         for (int hf = 0; hf < 2; ++hf) {
             const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
             const uint32_t pixOff = (uint32_t)(strip * 8) * p.nfast + hf * 32 + laneOff;
-            // bit (j*SLOTS + k): record index of a surviving triangle
-            const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u) << (j * SLOTS);
+            // bit k: triangle slot k of tile j survives in this region
+            const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
             if (act == 0) {
                 if (full)
                     storeBackground<IDS, true>(p, rgbTile, depthTile, idsTile, pixOff, fx0, fy);
@@ -1112,9 +1160,9 @@ void rasterGroupKernel(const RasterParams p)
             }
             if (!(p.debugSkip & 2u)) {
                 if (nearFree)
-                    rasterRegion<false, 4>(lds.planes, act, px, py, invNear, best, bid);
+                    rasterRegion<false, 4>(lds.planes, act, j * SLOTS, px, py, invNear, best, bid);
                 else
-                    rasterRegion<true, 4>(lds.planes, act, px, py, invNear, best, bid);
+                    rasterRegion<true, 4>(lds.planes, act, j * SLOTS, px, py, invNear, best, bid);
             }
             if (full)
                 storeRegion<IDS, true, TEX>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy,
@@ -1167,16 +1215,26 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         if (p.debugSlots >= slots && (p.debugSlots == 32 || p.debugSlots == 64))
             slots = p.debugSlots;                 // tuning aid (MRX_DEBUG_SLOTS)
         const uint32_t g = (uint32_t)(kChunk / slots);
-        const dim3 grid((items + g - 1) / g);
+        RasterParams q = p;
+        const uint32_t numGroups = (items + g - 1) / g;
+        // XCD-aware split.  Workgroups go round-robin to the eight XCDs and the
+        // odd XCD of every pair drains its stores ~15 % more slowly (measured,
+        // profiles/r01_xcd.txt): once the batch fills the chip, xcdSkew strips
+        // (eighths of a tile) per workgroup pair move from the odd to the even
+        // XCD (see the kernel prologue).
+        q.xcdSkew = (slots == 16 && numGroups >= 1024u) ? 3u : 0u;
+        if (p.xcdSkewWanted >= 0)
+            q.xcdSkew = slots == 16 ? (uint32_t)(p.xcdSkewWanted < 8 ? p.xcdSkewWanted : 7) : 0u;
+        const dim3 grid(numGroups);
         const dim3 gblock(kWave * groupWaves(p.anyTextured != 0));
 #define MRX_GROUP(S)                                                           \
     do {                                                                       \
         if (p.anyTextured) {                                                   \
-            if (ids) rasterGroupKernel<true, S, true><<<grid, gblock, 0, stream>>>(p);   \
-            else     rasterGroupKernel<false, S, true><<<grid, gblock, 0, stream>>>(p);  \
+            if (ids) rasterGroupKernel<true, S, true><<<grid, gblock, 0, stream>>>(q);   \
+            else     rasterGroupKernel<false, S, true><<<grid, gblock, 0, stream>>>(q);  \
         } else {                                                               \
-            if (ids) rasterGroupKernel<true, S, false><<<grid, gblock, 0, stream>>>(p);  \
-            else     rasterGroupKernel<false, S, false><<<grid, gblock, 0, stream>>>(p); \
+            if (ids) rasterGroupKernel<true, S, false><<<grid, gblock, 0, stream>>>(q);  \
+            else     rasterGroupKernel<false, S, false><<<grid, gblock, 0, stream>>>(q); \
         }                                                                      \
     } while (0)
         if (slots == 16) MRX_GROUP(16);

@@ -89,6 +89,11 @@ struct RasterParams {
     // production): 1 skip stores, 2 skip raster, 4 skip classification,
     // 8 skip triangle setup.  Outputs are wrong when any bit is set.
     uint32_t debugSkip;
+    // XCD-aware split of the group kernel (filled in by launchRaster);
+    // xcdSkew = strips moved per workgroup pair; xcdSkewWanted is the
+    // MRX_XCD_SKEW override: -1 automatic, 0 off, 1..7 strips.
+    uint32_t xcdSkew;
+    int32_t xcdSkewWanted;
     int32_t debugSlots;              // MRX_DEBUG_SLOTS: force 32 / 64 triangle slots per tile
     // Diagnostic only (MRX_DEBUG_STAMPS=1): per-wave s_memrealtime stamps,
     // [workgroup][wave][8], written to memory nothing else reads.

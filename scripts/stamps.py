@@ -47,3 +47,9 @@ cu_last = np.array([max(v) for v in per_cu.values()])
 print(f"distinct CUs seen {len(per_cu)}; WGs per CU {np.mean([len(v) for v in per_cu.values()]):.2f}; "
       f"mean spread of exits within a CU {within:.2f} us; per-CU last exit: min {cu_last.min():.1f} "
       f"p50 {np.median(cu_last):.1f} max {cu_last.max():.1f}")
+for i, nm in ((0, "entry"), (4, "after barrier")):
+    col = us[:, :, i].min(axis=1) if i == 0 else us[:, :, i].max(axis=1)
+    print(f"{nm} by XCC:", " ".join(f"{x}:{col[xcc == x].mean():.1f}/{col[xcc == x].max():.1f}" for x in sorted(set(xcc.tolist()))))
+print("WGs per XCC:", " ".join(f"{x}:{int((xcc == x).sum())}" for x in sorted(set(xcc.tolist()))))
+ids = np.nonzero(st[:, 0, 0] > 0)[0]
+print("WGs whose XCC differs from blockIdx % 8:", int((xcc != (ids % 8)).sum()), "of", len(ids))

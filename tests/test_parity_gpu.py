@@ -53,6 +53,22 @@ def test_synthetic_scenes(native, kw):
     _parity(scenes.synthetic_scene(**kw))
 
 
+@pytest.mark.parametrize("strips", [1, 3, 7])
+@pytest.mark.parametrize("kw", [
+    dict(num_worlds=64),
+    dict(num_worlds=7),                                  # odd workgroup count: unpaired last group
+    dict(num_worlds=9, textured=True),                   # four-wave variant, second classify pass
+    dict(num_worlds=5, width=96, height=40),             # pairs straddle views, ragged tiles
+    dict(num_worlds=3, width=130, height=70, render_mode="Raytracer"),
+], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_xcd_aware_split_forced_on_small_batches(native, monkeypatch, kw, strips):
+    # the split that moves strips between the workgroups of a pair (odd -> even
+    # XCD) normally starts at 4096 tiles; force it so that small, ragged batches
+    # exercise the five-tile workgroups as well
+    monkeypatch.setenv("MRX_XCD_SKEW", str(strips))
+    _parity(scenes.synthetic_scene(**kw))
+
+
 def test_headline_config_full_size(native):
     # BASELINE north star: 4096 worlds x 64x64 -- every pixel of every view
     desc = scenes.synthetic_scene(4096)
