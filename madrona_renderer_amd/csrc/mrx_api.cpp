@@ -482,11 +482,17 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.debugStamps = nullptr;
     if (const char *dbg = std::getenv("MRX_DEBUG_STAMPS"))
         if (std::atoi(dbg) != 0) {
-            const size_t n = (size_t)nviews * p.tilesFast * p.tilesSlow * 4 * 8;
+            const size_t n = ((size_t)nviews * p.tilesFast * p.tilesSlow + 64) * 4 * 8;
             MRX_HIP(r.stamps.alloc(n));
             MRX_HIP(hipMemset(r.stamps.ptr, 0, n * sizeof(unsigned long long)));
             p.debugStamps = r.stamps.ptr;
         }
+    p.grpViews = p.grpChunkTiles = p.grpPerView = 0;
+    p.grpViewsWanted = p.grpTilesWanted = 0;
+    if (const char *dbg = std::getenv("MRX_GROUP_VIEWS"))
+        p.grpViewsWanted = std::atoi(dbg);
+    if (const char *dbg = std::getenv("MRX_GROUP_TILES"))
+        p.grpTilesWanted = std::atoi(dbg);
     p.xcdSkew = 0;
     p.xcdSkewWanted = -1;
     if (const char *dbg = std::getenv("MRX_XCD_SKEW"))

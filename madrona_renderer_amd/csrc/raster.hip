@@ -17,6 +17,7 @@
 // where the spec writes fma().  The CPU oracle (oracle/raster_oracle.c) is a
 // separate restatement of the same spec and is never linked here.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "raster.hpp"
 
@@ -809,18 +810,22 @@ void rasterChunkedKernel(const RasterParams p)
 //   R+O all waves pull (tile, strip) items off an LDS counter, rasterise the
 //       strip's two regions and store them.
 // ---------------------------------------------------------------------------
-// A group is normally kChunk records (G = kChunk / SLOTS tiles); with the
-// XCD-aware split a workgroup on a fast XCD carries one 16-slot tile more.
+// A group is up to kGroupTilesMax tiles drawn from one or more views whose
+// triangles fit kChunk records together (setup is per view, shared by the
+// view's tiles); with the XCD-aware split a workgroup on a fast XCD carries
+// one 16-slot view more.
 constexpr int kGroupRecs = kChunk + 16;
-constexpr int kGroupTilesMax = 5;
+constexpr int kGroupTilesMax = 16;
 constexpr int kBackground = kGroupRecs;   // record index of "nothing hit"
 
 struct GroupLds {
     float planes[kGroupRecs][16];       // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | bbox
-    uint32_t masks[kGroupRecs];         // region bits 0..15, near-free bits 16..19, live bit 31
+    uint32_t live[kGroupRecs];          // record holds a triangle that can be visible
     float shade[kGroupRecs + 1][4];     // rgba, texture, objectID, world-local index
     float cold[kGroupRecs][kCold];      // u/v planes, lit colour
-    uint32_t tileInfo[kGroupTilesMax][4];   // per tile of the group: view, x0, y0, flags
+    // per (tile, slot of the tile's view): region bits 0..15, near-free bits 16..19
+    uint32_t masks[kGroupTilesMax * kChunk];
+    uint32_t tileInfo[kGroupTilesMax][4];   // view, x0, y0, flags | first record << 8
     uint32_t nextItem;                  // (tile, strip) work counter of phase R
 };
 constexpr uint32_t kTileValid = 4u;
@@ -921,30 +926,45 @@ template <bool IDS, int SLOTS, bool TEX>
 __global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? 4 : 8)
 void rasterGroupKernel(const RasterParams p)
 {
-    constexpr int G = kChunk / SLOTS;
     __shared__ GroupLds lds;
     // readfirstlane: the compiler cannot see that threadIdx.x / 64 is
     // wave-uniform and would predicate every `wave` branch instead of jumping
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
     const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
-    const uint32_t numItems = p.numViews * tilesPerView;
-    // XCD-aware split (see launchRaster): workgroup b runs on XCD b % 8 and
-    // the odd XCD of each pair drains its stores more slowly.  Workgroups 2m
-    // and 2m+1 share the tile between their two runs of four: the odd one
-    // leaves its first p.xcdSkew strips to the even one (both set the tile up).
-    const uint32_t item0 = blockIdx.x * G;
-    uint32_t groupTiles = G, firstStrip = 0, numStrips = G * 8;
+    // ---- which views / tiles this workgroup owns (launchRaster):
+    //  A  grpPerView == 1: grpViews whole views (all their tiles);
+    //  B  otherwise: grpChunkTiles tiles of one view.
+    uint32_t firstView, groupViews, firstTile, groupTiles;
+    if (p.grpPerView == 1) {
+        firstView = blockIdx.x * p.grpViews;
+        groupViews = p.grpViews;
+        firstTile = 0;
+        groupTiles = groupViews * tilesPerView;
+    } else {
+        firstView = blockIdx.x / p.grpPerView;
+        groupViews = 1;
+        firstTile = (blockIdx.x - firstView * p.grpPerView) * p.grpChunkTiles;
+        groupTiles = min(p.grpChunkTiles, tilesPerView - firstTile);
+    }
+    // XCD-aware split (see launchRaster; one-tile views, four per group):
+    // workgroup b runs on XCD b % 8 and the odd XCD of each pair drains its
+    // stores more slowly.  Workgroups 2m and 2m+1 share the view between their
+    // two runs of four: the odd one leaves its first p.xcdSkew strips to the
+    // even one (both set the view up).
+    uint32_t firstStrip = 0, numStrips = groupTiles * 8;
     if (SLOTS == 16 && p.xcdSkew) {
         if (blockIdx.x & 1u) {
             firstStrip = p.xcdSkew;
             numStrips -= p.xcdSkew;
         } else {
-            groupTiles = G + 1;
+            groupViews += 1;
+            groupTiles += 1;
             numStrips += p.xcdSkew;
         }
     }
-    const int groupRecs = (int)groupTiles * SLOTS;
+    const int groupRecs = (int)groupViews * SLOTS;
+    const int numPairs = (int)groupTiles * SLOTS;
     const float invNear = p.invNear, invFar = p.invFar;
     if (p.debugSkip & 16u)
         return;                                   // timing aid: bare launch
@@ -956,33 +976,22 @@ void rasterGroupKernel(const RasterParams p)
             stamps[i] = __builtin_amdgcn_s_memrealtime();                      \
     } while (0)
     MRX_STAMP(0);
+    for (int i = threadIdx.x; i < numPairs; i += groupWaves(TEX) * kWave)
+        lds.masks[i] = 0u;
 
-    // ---- S1: wave 0 (and wave 1 for a fifth tile), lane = (tile j of the
-    //      group, triangle slot k): setup
+    // ---- S1: one lane per (view vi of the group, triangle slot k): setup.
+    //      Wave 0 covers the first 64 records, wave 1 a fifth 16-slot view.
     if (wave * kWave < groupRecs) {
         const int rec = wave * kWave + lane;
-        const int j = rec / SLOTS, k = rec % SLOTS;
-        const uint32_t item = item0 + j;
+        const int vi = rec / SLOTS, k = rec % SLOTS;
         const bool recOk = rec < groupRecs;
-        const bool tileOk = item < numItems && recOk;
-        TileCtx t;
-        // integer divisions cost ~25 VALU each: real (scalar) branches around
-        // them for the common one-tile-per-view / one-camera-per-world cases
-        t.view = tileOk ? item : 0u;
-        t.tileX0 = t.tileY0 = 0u;
-        if (tilesPerView != 1) {
-            t.view = tileOk ? item / tilesPerView : 0u;
-            const uint32_t tile = tileOk ? item - t.view * tilesPerView : 0u;
-            const uint32_t ty = tile / p.tilesFast;
-            t.tileX0 = (tile - ty * p.tilesFast) * 64u;
-            t.tileY0 = ty * 64u;
-        }
-        t.triBegin = t.view * p.viewTriStride;
-        t.lx = t.ly = 0;
+        const bool viewOk = recOk && firstView + vi < p.numViews;
+        const uint32_t view = viewOk ? firstView + vi : 0u;
         // everything addressed by the view index is requested up front; the
         // pose / geometry rows one level down follow as soon as wt arrives --
         // or at once, when the draw list is arithmetic (uniform worlds)
         WorldTri wt;
+        uint32_t numTris;
         if (p.uniInstances) {
             const uint32_t kk = (uint32_t)k;
             const uint32_t li = (kk >= p.uniPrefix[1] ? 1u : 0u) + (kk >= p.uniPrefix[2] ? 1u : 0u) +
@@ -991,28 +1000,30 @@ void rasterGroupKernel(const RasterParams p)
                                : li == 2 ? p.uniPrefix[2] : p.uniPrefix[3];
             const uint32_t first = li == 0 ? p.uniFirstTri[0] : li == 1 ? p.uniFirstTri[1]
                                  : li == 2 ? p.uniFirstTri[2] : p.uniFirstTri[3];
-            uint32_t world = t.view;
+            // integer divisions cost ~25 VALU each: a real (scalar) branch
+            // around this one for the common one-camera-per-world case
+            uint32_t world = view;
             if (p.uniCamsPerWorld != 1)
-                world = t.view / p.uniCamsPerWorld;
+                world = view / p.uniCamsPerWorld;
             wt.inst = world * p.uniInstances + li;
             wt.tri = first + (kk - pre);
-            t.numTris = tileOk ? p.uniPrefix[4] : 0u;
+            numTris = viewOk ? p.uniPrefix[4] : 0u;
             if (kk >= p.uniPrefix[4]) {           // idle slot: keep the loads in range
                 wt.inst = 0;
                 wt.tri = 0;
             }
         } else {
             // slots past the view's row are idle: keep their load inside the row
-            wt = p.viewTris[t.triBegin + ((uint32_t)k < p.viewTriStride ? (uint32_t)k : 0u)];
-            t.numTris = tileOk ? p.viewTriCount[t.view] : 0u;
+            wt = p.viewTris[view * p.viewTriStride + ((uint32_t)k < p.viewTriStride ? (uint32_t)k : 0u)];
+            numTris = viewOk ? p.viewTriCount[view] : 0u;
         }
         ViewConst vc;
         {
-            const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * t.view);
+            const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * view);
             quatToMat(q.x, q.y, q.z, q.w, vc.Rc);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                vc.c[r] = p.camPos[3 * t.view + r];
+                vc.c[r] = p.camPos[3 * view + r];
                 vc.lv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r],
                                 p.toLight[0], p.toLight[1], p.toLight[2]);
             }
@@ -1025,7 +1036,7 @@ void rasterGroupKernel(const RasterParams p)
         MRX_STAMP(1);
         if (recOk) {
             lds.shade[rec][1] = __int_as_float(-1);
-            if ((uint32_t)k < t.numTris && !(p.debugSkip & 8u))
+            if ((uint32_t)k < numTris && !(p.debugSkip & 8u))
                 valid = setupTriangle(p, vc, wt, k, c, lds.shade[rec], lds.cold[rec]);
             MRX_STAMP(2);
             float4 *dst = reinterpret_cast<float4 *>(lds.planes[rec]);
@@ -1033,14 +1044,7 @@ void rasterGroupKernel(const RasterParams p)
             dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
             dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
             dst[3] = make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1);
-            // bit 31 marks a live triangle until classification replaces the word
-            lds.masks[rec] = (valid && !(p.debugSkip & 4u)) ? 0x80000000u : 0u;
-            if (k == 0) {
-                lds.tileInfo[j][0] = t.view;
-                lds.tileInfo[j][1] = t.tileX0;
-                lds.tileInfo[j][2] = t.tileY0;
-                lds.tileInfo[j][3] = tileOk ? kTileValid : 0u;
-            }
+            lds.live[rec] = (valid && !(p.debugSkip & 4u)) ? 1u : 0u;
         }
         if (rec == 0) {
             lds.nextItem = 0;
@@ -1049,19 +1053,38 @@ void rasterGroupKernel(const RasterParams p)
             lds.shade[kBackground][2] = __int_as_float(-1);
             lds.shade[kBackground][3] = __int_as_float(-1);
         }
+    } else if (wave == 3) {
+        // meanwhile: where each tile of the group lies
+        if (lane < (int)groupTiles) {
+            uint32_t vi = (uint32_t)lane, tile = firstTile;
+            if (tilesPerView != 1) {
+                vi = groupViews == 1 ? 0u : (uint32_t)lane / tilesPerView;
+                tile = firstTile + (uint32_t)lane - vi * tilesPerView;
+            }
+            const uint32_t ty = tilesPerView != 1 ? tile / p.tilesFast : 0u;
+            lds.tileInfo[lane][0] = firstView + vi;
+            lds.tileInfo[lane][1] = (tile - ty * p.tilesFast) * 64u;
+            lds.tileInfo[lane][2] = ty * 64u;
+            lds.tileInfo[lane][3] = (firstView + vi < p.numViews ? kTileValid : 0u) | ((vi * SLOTS) << 8);
+        }
     }
     __syncthreads();
     MRX_STAMP(3);
 
-    // ---- S2: waves 0-3 each classify two strips (four 32x8 regions) of every
-    //      triangle (lane = the same (tile, slot) as in S1), results OR-ed in LDS:
-    //      bits 0..15 regions, bits 16..19 "near-free over this wave's strips".
-    //      A fifth tile's records go to waves 4-7, or to a second pass.
-    constexpr int kClassifyStride = (groupWaves(TEX) / 4) * kWave;
-    for (int rec = (wave >> 2) * kWave + lane; rec - lane < groupRecs; rec += kClassifyStride) {
-        if (rec >= groupRecs || !(lds.masks[rec] & 0x80000000u))
+    // ---- S2: classification of every (tile, triangle slot) pair against the
+    //      tile's sixteen 32x8 regions.  Wave w takes strips 2(w&3), 2(w&3)+1
+    //      (four regions) of the pairs (w>>2)*64 + lane, + 64 * (waves / 4), ...;
+    //      results are OR-ed in LDS: bits 0..15 regions, bits 16..19
+    //      "near-free over this wave's strips".
+    constexpr int kPairStride = (groupWaves(TEX) / 4) * kWave;
+    for (int pair = (wave >> 2) * kWave + lane; pair - lane < numPairs; pair += kPairStride) {
+        if (pair >= numPairs)
             continue;
-        const int j = rec / SLOTS;
+        const int j = pair / SLOTS, k = pair % SLOTS;
+        const uint32_t info = lds.tileInfo[j][3];
+        const int rec = (int)(info >> 8) + k;
+        if (!(info & kTileValid) || !lds.live[rec])
+            continue;
         const float4 *src = reinterpret_cast<const float4 *>(lds.planes[rec]);
         const float4 a = src[0], b = src[1], cc = src[2], bb = src[3];
         TriPlanes c;
@@ -1081,7 +1104,7 @@ void rasterGroupKernel(const RasterParams p)
         if (nearOk)
             m |= 1u << (16 + (wave & 3));
         if (m)
-            atomicOr(&lds.masks[rec], m);
+            atomicOr(&lds.masks[pair], m);
     }
     __syncthreads();
     MRX_STAMP(4);
@@ -1093,7 +1116,7 @@ void rasterGroupKernel(const RasterParams p)
     // region with fully linear 1 KiB stores was measured slower: no x culling)
     const int lx = lane & 7, ly = lane >> 3;
     const uint32_t laneOff = (uint32_t)ly * p.nfast + 4u * lx;
-    int cachedTile = -1;
+    int cachedTile = -1, recBase = 0;
     uint32_t view = 0, tileX0 = 0, tileY0 = 0, mask = 0;
     float pxTile[2][kRegionBlocks] = {};
     bool anyTex = false, nearFree = false, full = false;
@@ -1111,9 +1134,10 @@ void rasterGroupKernel(const RasterParams p)
         const int j = (int)(item >> 3), strip = (int)(item & 7u);
         if (j != cachedTile) {
             cachedTile = j;
-            const uint32_t flags = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][3]);
-            if (!(flags & kTileValid))
-                break;                              // tiles past the end of the batch
+            const uint32_t info = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][3]);
+            if (!(info & kTileValid))
+                break;                              // views past the end of the batch
+            recBase = (int)(info >> 8);
             view = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][0]);
             tileX0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][1]);
             tileY0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][2]);
@@ -1124,7 +1148,7 @@ void rasterGroupKernel(const RasterParams p)
             full = (p.nfast & 3u) == 0 && tileX0 + 64u <= p.nfast && tileY0 + 64u <= p.nslow;
             // lane k < SLOTS looks at the region mask of triangle slot k of tile j
             mask = lane < SLOTS ? lds.masks[j * SLOTS + lane] : 0u;
-            const int32_t tex = lane < SLOTS ? __float_as_int(lds.shade[j * SLOTS + lane][1]) : -1;
+            const int32_t tex = lane < SLOTS ? __float_as_int(lds.shade[recBase + lane][1]) : -1;
             anyTex = __ballot((mask & 0xFFFFu) != 0 && tex >= 0) != 0;
             // every surviving triangle stays behind the near plane over the
             // whole tile: the per-pixel near test is dropped for the tile
@@ -1141,7 +1165,7 @@ void rasterGroupKernel(const RasterParams p)
         for (int hf = 0; hf < 2; ++hf) {
             const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
             const uint32_t pixOff = (uint32_t)(strip * 8) * p.nfast + hf * 32 + laneOff;
-            // bit k: triangle slot k of tile j survives in this region
+            // bit k: triangle slot k of the tile's view survives in this region
             const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
             if (act == 0) {
                 if (full)
@@ -1160,9 +1184,9 @@ void rasterGroupKernel(const RasterParams p)
             }
             if (!(p.debugSkip & 2u)) {
                 if (nearFree)
-                    rasterRegion<false, 4>(lds.planes, act, j * SLOTS, px, py, invNear, best, bid);
+                    rasterRegion<false, 4>(lds.planes, act, recBase, px, py, invNear, best, bid);
                 else
-                    rasterRegion<true, 4>(lds.planes, act, j * SLOTS, px, py, invNear, best, bid);
+                    rasterRegion<true, 4>(lds.planes, act, recBase, px, py, invNear, best, bid);
             }
             if (full)
                 storeRegion<IDS, true, TEX>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy,
@@ -1206,25 +1230,51 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         if (ids) rasterChunkedKernel<true><<<dim3(items), block, 0, stream>>>(p);
         else     rasterChunkedKernel<false><<<dim3(items), block, 0, stream>>>(p);
     } else {
-        // dense setup: 64 / SLOTS tiles per workgroup
+        // triangle slots per view: the smallest of 16 / 32 / 64 that holds a world
         int slots = maxWorldTris <= 16 ? 16 : maxWorldTris <= 32 ? 32 : 64;
-        // small batches: fewer tiles per workgroup so that every CU still gets
-        // about four workgroups (the group's tiles are walked one after another)
-        while (slots < 64 && (uint64_t)items * (uint32_t)slots < 64ull * 1024ull)
-            slots *= 2;
         if (p.debugSlots >= slots && (p.debugSlots == 32 || p.debugSlots == 64))
             slots = p.debugSlots;                 // tuning aid (MRX_DEBUG_SLOTS)
-        const uint32_t g = (uint32_t)(kChunk / slots);
+        // Workgroup shape.  Setup is per view and the view's tiles share it, so
+        // a workgroup takes as many whole views as fit 64 records and 16 tiles;
+        // a view of more than 16 tiles is cut into chunks of 16.  Small batches
+        // shrink the workgroups again until there are ~4 per CU.
+        const uint32_t tpv = p.tilesFast * p.tilesSlow;
+        constexpr uint32_t kFill = 1024;          // 256 CUs x 4 resident workgroups
         RasterParams q = p;
-        const uint32_t numGroups = (items + g - 1) / g;
+        uint32_t vg = 1, ct = tpv, gpv = 1;
+        if (tpv <= (uint32_t)kGroupTilesMax) {
+            vg = std::min<uint32_t>((uint32_t)(kChunk / slots), (uint32_t)kGroupTilesMax / tpv);
+            while (vg > 1 && (p.numViews + vg - 1) / vg < kFill)
+                vg /= 2;
+        } else {
+            ct = (uint32_t)kGroupTilesMax;
+        }
+        if (vg == 1)
+            while (ct > 1 && (uint64_t)p.numViews * ((tpv + ct - 1) / ct) < kFill)
+                ct = (ct + 1) / 2;
+        if (p.grpViewsWanted > 0 && tpv * (uint32_t)p.grpViewsWanted <= (uint32_t)kGroupTilesMax &&
+            p.grpViewsWanted * slots <= kChunk) {
+            vg = (uint32_t)p.grpViewsWanted;
+            ct = tpv;
+        }
+        if (p.grpTilesWanted > 0 && p.grpTilesWanted <= kGroupTilesMax) {
+            vg = 1;
+            ct = std::min<uint32_t>((uint32_t)p.grpTilesWanted, tpv);
+        }
+        gpv = (tpv + ct - 1) / ct;
+        q.grpViews = vg;
+        q.grpChunkTiles = ct;
+        q.grpPerView = gpv;
+        const uint32_t numGroups = gpv == 1 ? (p.numViews + vg - 1) / vg : p.numViews * gpv;
         // XCD-aware split.  Workgroups go round-robin to the eight XCDs and the
         // odd XCD of every pair drains its stores ~15 % more slowly (measured,
         // profiles/r01_xcd.txt): once the batch fills the chip, xcdSkew strips
         // (eighths of a tile) per workgroup pair move from the odd to the even
         // XCD (see the kernel prologue).
-        q.xcdSkew = (slots == 16 && numGroups >= 1024u) ? 3u : 0u;
+        const bool skewable = slots == 16 && tpv == 1 && vg == 4;
+        q.xcdSkew = (skewable && numGroups >= kFill) ? 3u : 0u;
         if (p.xcdSkewWanted >= 0)
-            q.xcdSkew = slots == 16 ? (uint32_t)(p.xcdSkewWanted < 8 ? p.xcdSkewWanted : 7) : 0u;
+            q.xcdSkew = skewable ? (uint32_t)(p.xcdSkewWanted < 8 ? p.xcdSkewWanted : 7) : 0u;
         const dim3 grid(numGroups);
         const dim3 gblock(kWave * groupWaves(p.anyTextured != 0));
 #define MRX_GROUP(S)                                                           \

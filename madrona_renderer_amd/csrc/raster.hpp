@@ -89,6 +89,13 @@ struct RasterParams {
     // production): 1 skip stores, 2 skip raster, 4 skip classification,
     // 8 skip triangle setup.  Outputs are wrong when any bit is set.
     uint32_t debugSkip;
+    // Shape of the group kernel's workgroups (filled in by launchRaster):
+    // grpPerView == 1: a workgroup owns grpViews whole views; otherwise it owns
+    // grpChunkTiles tiles of one view and a view takes grpPerView workgroups.
+    // grpViewsWanted / grpTilesWanted: MRX_GROUP_VIEWS / MRX_GROUP_TILES
+    // tuning overrides (0 = automatic).
+    uint32_t grpViews, grpChunkTiles, grpPerView;
+    int32_t grpViewsWanted, grpTilesWanted;
     // XCD-aware split of the group kernel (filled in by launchRaster);
     // xcdSkew = strips moved per workgroup pair; xcdSkewWanted is the
     // MRX_XCD_SKEW override: -1 automatic, 0 off, 1..7 strips.
