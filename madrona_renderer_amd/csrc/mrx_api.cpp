@@ -487,6 +487,9 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             MRX_HIP(hipMemset(r.stamps.ptr, 0, n * sizeof(unsigned long long)));
             p.debugStamps = r.stamps.ptr;
         }
+    p.writeThrough = 1;
+    if (const char *dbg = std::getenv("MRX_WRITE_THROUGH"))
+        p.writeThrough = std::atoi(dbg) != 0;
     p.grpViews = p.grpChunkTiles = p.grpPerView = 0;
     p.grpViewsWanted = p.grpTilesWanted = 0;
     if (const char *dbg = std::getenv("MRX_GROUP_VIEWS"))

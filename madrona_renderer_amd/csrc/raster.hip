@@ -657,17 +657,24 @@ __device__ __forceinline__ void rasterRegion(const float (*planes)[16], uint64_t
 // overlaps it (scripts/micro/store_modes.hip: 3.1 us -> 0.9 us between
 // back-to-back 128 MiB launches).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void streamStore16(void *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+__device__ __forceinline__ void streamStore16(uint32_t writeThrough, void *dst,
+                                              uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     const u32x4 v = { a, b, c, d };
     // s_nop 1: on gfx940+ a VALU write to the data registers of a >64-bit store
     // needs two wait states after it; the compiler cannot see into the asm to
     // insert them (one is not enough: dword 2 of the data was overwritten)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    if (writeThrough)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
 }
-__device__ __forceinline__ void streamStore4(void *dst, uint32_t a)
+__device__ __forceinline__ void streamStore4(uint32_t writeThrough, void *dst, uint32_t a)
 {
-    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(dst), "v"(a) : "memory");
+    if (writeThrough)
+        asm volatile("global_store_dword %0, %1, off sc1" :: "v"(dst), "v"(a) : "memory");
+    else
+        asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(a) : "memory");
 }
 
 // Store a region whose pixels are already shaded (chunked kernel).  A lane owns
@@ -688,19 +695,19 @@ __device__ __forceinline__ void outputRegion(const RasterParams &p, const TileCt
         return;
     const size_t o = ((size_t)t.view * p.nslow + fy) * p.nfast + fx0;
     if ((p.nfast & 3u) == 0 && fx0 + 3 < p.nfast) {
-        streamStore16(p.rgb + o, rgba[0], rgba[1], rgba[2], rgba[3]);
-        streamStore16(p.depth + o, __float_as_uint(dep[0]), __float_as_uint(dep[1]),
+        streamStore16(p.writeThrough, p.rgb + o, rgba[0], rgba[1], rgba[2], rgba[3]);
+        streamStore16(p.writeThrough, p.depth + o, __float_as_uint(dep[0]), __float_as_uint(dep[1]),
                       __float_as_uint(dep[2]), __float_as_uint(dep[3]));
         if (IDS)
-            streamStore16(p.ids + o, (uint32_t)id[0], (uint32_t)id[1], (uint32_t)id[2], (uint32_t)id[3]);
+            streamStore16(p.writeThrough, p.ids + o, (uint32_t)id[0], (uint32_t)id[1], (uint32_t)id[2], (uint32_t)id[3]);
     } else {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             if (fx0 + b < p.nfast) {
-                streamStore4(p.rgb + o + b, rgba[b]);
-                streamStore4(p.depth + o + b, __float_as_uint(dep[b]));
+                streamStore4(p.writeThrough, p.rgb + o + b, rgba[b]);
+                streamStore4(p.writeThrough, p.depth + o + b, __float_as_uint(dep[b]));
                 if (IDS)
-                    streamStore4(p.ids + o + b, (uint32_t)id[b]);
+                    streamStore4(p.writeThrough, p.ids + o + b, (uint32_t)id[b]);
             }
         }
     }
@@ -872,19 +879,19 @@ __device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLd
     if (p.debugSkip & 1u)
         return;
     if (FULL) {
-        streamStore16(rgbTile + pixOff, rgba[0], rgba[1], rgba[2], rgba[3]);
-        streamStore16(depthTile + pixOff, __float_as_uint(dep[0]), __float_as_uint(dep[1]),
+        streamStore16(p.writeThrough, rgbTile + pixOff, rgba[0], rgba[1], rgba[2], rgba[3]);
+        streamStore16(p.writeThrough, depthTile + pixOff, __float_as_uint(dep[0]), __float_as_uint(dep[1]),
                       __float_as_uint(dep[2]), __float_as_uint(dep[3]));
         if (IDS)
-            streamStore16(idsTile + pixOff, (uint32_t)id[0], (uint32_t)id[1], (uint32_t)id[2], (uint32_t)id[3]);
+            streamStore16(p.writeThrough, idsTile + pixOff, (uint32_t)id[0], (uint32_t)id[1], (uint32_t)id[2], (uint32_t)id[3]);
     } else if (fy < p.nslow) {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             if (fx0 + b < p.nfast) {
-                streamStore4(rgbTile + pixOff + b, rgba[b]);
-                streamStore4(depthTile + pixOff + b, __float_as_uint(dep[b]));
+                streamStore4(p.writeThrough, rgbTile + pixOff + b, rgba[b]);
+                streamStore4(p.writeThrough, depthTile + pixOff + b, __float_as_uint(dep[b]));
                 if (IDS)
-                    streamStore4(idsTile + pixOff + b, (uint32_t)id[b]);
+                    streamStore4(p.writeThrough, idsTile + pixOff + b, (uint32_t)id[b]);
             }
         }
     }
@@ -900,18 +907,18 @@ __device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t 
         return;
     const uint32_t bg = 0xFF000000u;
     if (FULL) {
-        streamStore16(rgbTile + pixOff, bg, bg, bg, bg);
-        streamStore16(depthTile + pixOff, 0u, 0u, 0u, 0u);
+        streamStore16(p.writeThrough, rgbTile + pixOff, bg, bg, bg, bg);
+        streamStore16(p.writeThrough, depthTile + pixOff, 0u, 0u, 0u, 0u);
         if (IDS)
-            streamStore16(idsTile + pixOff, ~0u, ~0u, ~0u, ~0u);
+            streamStore16(p.writeThrough, idsTile + pixOff, ~0u, ~0u, ~0u, ~0u);
     } else if (fy < p.nslow) {
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             if (fx0 + b < p.nfast) {
-                streamStore4(rgbTile + pixOff + b, bg);
-                streamStore4(depthTile + pixOff + b, 0u);
+                streamStore4(p.writeThrough, rgbTile + pixOff + b, bg);
+                streamStore4(p.writeThrough, depthTile + pixOff + b, 0u);
                 if (IDS)
-                    streamStore4(idsTile + pixOff + b, ~0u);
+                    streamStore4(p.writeThrough, idsTile + pixOff + b, ~0u);
             }
         }
     }

@@ -89,6 +89,8 @@ struct RasterParams {
     // production): 1 skip stores, 2 skip raster, 4 skip classification,
     // 8 skip triangle setup.  Outputs are wrong when any bit is set.
     uint32_t debugSkip;
+    // Output store policy: 1 = write-through (sc1), 0 = plain write-back.
+    uint32_t writeThrough;
     // Shape of the group kernel's workgroups (filled in by launchRaster):
     // grpPerView == 1: a workgroup owns grpViews whole views; otherwise it owns
     // grpChunkTiles tiles of one view and a view takes grpPerView workgroups.
