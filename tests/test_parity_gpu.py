@@ -69,6 +69,34 @@ def test_xcd_aware_split_forced_on_small_batches(native, monkeypatch, kw, strips
     _parity(scenes.synthetic_scene(**kw))
 
 
+@pytest.mark.parametrize("env", [
+    {"MRX_GROUP_TILES": "1"}, {"MRX_GROUP_TILES": "3"}, {"MRX_GROUP_TILES": "16"},
+    {"MRX_GROUP_VIEWS": "1"}, {"MRX_GROUP_VIEWS": "2"}, {"MRX_GROUP_VIEWS": "4"},
+], ids=lambda e: "-".join(f"{k[10:]}{v}" for k, v in e.items()))
+@pytest.mark.parametrize("kw", [
+    dict(num_worlds=9, width=128, height=128, with_wall=True),          # 4 tiles / view, 32 slots
+    dict(num_worlds=5, width=200, height=72, textured=True),            # 8 ragged tiles / view
+    dict(num_worlds=3, width=256, height=256, textured=True, render_mode="Raytracer"),
+    dict(num_worlds=2, width=320, height=192),                          # 15 tiles / view
+    dict(num_worlds=1, width=384, height=320),                          # 30 tiles: chunks of a view
+], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_workgroup_shapes(native, monkeypatch, kw, env):
+    # whole views per workgroup (setup shared by the view's tiles) and chunks of
+    # one large view, including shapes the automatic choice would not pick
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _parity(scenes.synthetic_scene(**kw))
+
+
+def test_write_back_store_policy_gives_the_same_bytes(native, monkeypatch):
+    desc = scenes.synthetic_scene(num_worlds=40, with_wall=True, textured=True)
+    _, a, _ = _parity(desc)
+    monkeypatch.setenv("MRX_WRITE_THROUGH", "0")
+    _, b, _ = _parity(desc)
+    for k in ("rgb", "depth", "tri_id"):
+        assert np.array_equal(a[k], b[k])
+
+
 def test_headline_config_full_size(native):
     # BASELINE north star: 4096 worlds x 64x64 -- every pixel of every view
     desc = scenes.synthetic_scene(4096)
