@@ -15,8 +15,11 @@ for name, kw in CONFIGS:
     t0 = time.time()
     d = scenes.synthetic_scene(**kw)
     r = scenes.make_renderer(d)
-    r.time_renders(5)
-    ms = min(r.time_renders(20) for _ in range(3)) / 20
+    t1 = time.time()
+    while time.time() - t1 < 0.25:               # let the clocks settle
+        r.time_renders(50)
+    n = 400 if d.num_views * d.width * d.height < 2 ** 27 else 50
+    ms = sorted(r.time_renders(n) for _ in range(5))[2] / n
     b = r.bytes_per_step()
     print(f"{name:34s} {ms * 1000:9.1f} us/step  {d.num_views / ms * 1000:11.3e} views/s  "
           f"{b / ms / 1e9:6.2f} TB/s  ({b / 2**20:7.0f} MiB/step, setup {time.time() - t0:.1f}s)", flush=True)
