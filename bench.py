@@ -81,10 +81,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # MRX_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo for the barriers --
+    # rehearses the N>1 control flow on a one-GPU box (the numbers mean nothing)
+    rehearsal = os.environ.get("MRX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n_gpus = world if world > 1 else 1
     if a.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {a.gpus} but WORLD_SIZE={world}; using {n_gpus}",
@@ -108,7 +116,7 @@ def main():
     for _ in range(a.warmup):
         r.step()
     wall, dev_ms = timed_steps(r, a.steps, barrier)
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
