@@ -39,10 +39,6 @@ struct WaveLds {
     float hot[kChunk][kHot];     // [0..11] planes (brute only), [12..15] shade
     float cold[kChunk][kCold];
 };
-struct WaveLdsCompact {
-    float shade[kChunk][4];      // rgba, texture, objectID, world-local index
-    float cold[kChunk][kCold];   // u/v planes, lit colour
-};
 
 // S2: every 3-term dot product is one rounded product and two fused steps
 __device__ __forceinline__ float dot3(float ax, float ay, float az,
@@ -355,7 +351,6 @@ __device__ __forceinline__ uint64_t setupChunk(const RasterParams &p, const View
 
 // Winner lookup + shading of one pixel (lane) of block b.
 __device__ __forceinline__ const float *shadeRec(const WaveLds &L, int32_t w) { return &L.hot[w][12]; }
-__device__ __forceinline__ const float *shadeRec(const WaveLdsCompact &L, int32_t w) { return L.shade[w]; }
 
 template <bool IDS, typename LDS>
 __device__ __forceinline__ void resolvePixel(const RasterParams &p, const LDS &L,
@@ -489,6 +484,11 @@ void rasterBruteKernel(const RasterParams p)
     }
 }
 
+// Bits 0..15: the tile's 32x8 regions (bit 2*strip + half) the lane's triangle
+// can touch.  Bit 16: the 1/depth plane stays <= invNear over the whole tile,
+// so the per-pixel near test can be dropped for this triangle.
+constexpr uint32_t kNearFree = 1u << 16;
+
 // ---------------------------------------------------------------------------
 // Wave-level binning.  The lane that set a triangle up classifies the tile's
 // sixteen 32x8-pixel regions against it: a region is dropped when one edge
@@ -499,29 +499,6 @@ void rasterBruteKernel(const RasterParams p)
 // is the value at one of its corner pixels and dropping a region cannot change
 // any pixel: binning only skips work.
 // ---------------------------------------------------------------------------
-// S3-S7 for the lane's triangle; planes stay in registers, the shading record
-// goes to LDS.  Returns validity.
-__device__ __forceinline__ bool setupLane(const RasterParams &p, const ViewConst &vc,
-                                          const TileCtx &t, uint32_t chunk, int lane,
-                                          WaveLdsCompact &L, TriPlanes &c)
-{
-    bool valid = false;
-    const uint32_t k = chunk + lane;
-    c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
-    c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
-    c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
-    if (k < t.numTris && !(p.debugSkip & 8u)) {
-        const WorldTri wt = p.viewTris[t.triBegin + k];
-        valid = setupTriangle(p, vc, wt, (int32_t)k, c, L.shade[lane], L.cold[lane]);
-    }
-    return valid;
-}
-
-// Bits 0..15: the tile's 32x8 regions (bit 2*strip + half) the lane's triangle
-// can touch.  Bit 16: the 1/depth plane stays <= invNear over the whole tile,
-// so the per-pixel near test can be dropped for this triangle.
-constexpr uint32_t kNearFree = 1u << 16;
-
 // Region bits of strips [S0, S1) for the lane's triangle; `nearOk` reports
 // whether the 1/depth plane stays <= invNear over those strips.
 template <int S0, int S1>
@@ -715,16 +692,23 @@ __device__ __forceinline__ void outputRegion(const RasterParams &p, const TileCt
 
 // ---------------------------------------------------------------------------
 // Worlds with more than 64 triangles: one workgroup = one 64x64 tile, the
-// triangles go through LDS in chunks of 64.  Wave 0 sets up and classifies a
-// chunk (lane = triangle) and publishes planes + region mask; after the
-// barrier every wave rasterises its own two 64x8 strips against the chunk and
-// shades the chunk's winners before the next chunk replaces the records.
-// Correct and tested, not tuned: large meshes are BVH territory.
+// triangles go through LDS in passes of 256.  In a pass every wave sets up and
+// classifies 64 triangles (lane = triangle) and publishes planes + region
+// mask; after the barrier every wave rasterises its own two 64x8 strips
+// against the 256 records and shades the pass's winners before the next pass
+// replaces the records.  Large meshes proper are BVH territory.
 // ---------------------------------------------------------------------------
-struct TileLds {
-    float planes[kChunk][16];    // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | mask
-    WaveLdsCompact rec;          // shading records
+constexpr int kPass = kChunk * kWavesPerBlock;    // triangles per pass
+
+struct PassRecs {
+    float shade[kPass][4];       // rgba, texture, objectID, world-local index
+    float cold[kPass][kCold];    // u/v planes, lit colour
 };
+struct TileLds {
+    float planes[kPass][16];     // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | mask
+    PassRecs rec;                // shading records
+};
+__device__ __forceinline__ const float *shadeRec(const PassRecs &L, int32_t w) { return L.shade[w]; }
 
 template <bool IDS>
 __global__ __launch_bounds__(kWave *kWavesPerBlock, 3)
@@ -754,16 +738,28 @@ void rasterChunkedKernel(const RasterParams p)
             outId[g][b] = -1;
         }
 
-    for (uint32_t chunk = 0; chunk < t.numTris; chunk += kChunk) {
-        if (chunk != 0)
-            __syncthreads();                      // previous chunk fully consumed
-        if (wave == 0) {
+    for (uint32_t pass = 0; pass < t.numTris; pass += kPass) {
+        if (pass != 0)
+            __syncthreads();                      // previous pass fully consumed
+        {
+            const int rec = wave * kWave + lane;
+            const uint32_t k = pass + (uint32_t)rec;
             TriPlanes c;
+            c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
+            c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
+            c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
             uint32_t mask = 0;
-            const bool valid = setupLane(p, vc, t, chunk, lane, lds.rec, c);
-            if (valid && !(p.debugSkip & 4u))
-                mask = classifyRegions(c, t, invNear, invFar);
-            float4 *dst = reinterpret_cast<float4 *>(lds.planes[lane]);
+            // whole waves past the end of the list skip the setup code
+            if (pass + (uint32_t)(wave * kWave) < t.numTris) {
+                bool valid = false;
+                if (k < t.numTris && !(p.debugSkip & 8u)) {
+                    const WorldTri wt = p.viewTris[t.triBegin + k];
+                    valid = setupTriangle(p, vc, wt, (int32_t)k, c, lds.rec.shade[rec], lds.rec.cold[rec]);
+                }
+                if (valid && !(p.debugSkip & 4u))
+                    mask = classifyRegions(c, t, invNear, invFar);
+            }
+            float4 *dst = reinterpret_cast<float4 *>(lds.planes[rec]);
             dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
             dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
             dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
@@ -771,8 +767,8 @@ void rasterChunkedKernel(const RasterParams p)
         }
         __syncthreads();
 
-        // lane k looks at triangle k's region mask; planes are read per visit
-        const uint32_t mask = __float_as_uint(lds.planes[lane][12]);
+        const uint32_t left = t.numTris - pass;
+        const int subs = left >= (uint32_t)kPass ? kWavesPerBlock : (int)((left + kWave - 1) / kWave);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int strip = 2 * wave + (g >> 1), hf = g & 1;
@@ -783,10 +779,15 @@ void rasterChunkedKernel(const RasterParams p)
 #pragma unroll
             for (int b = 0; b < kRegionBlocks; ++b)
                 px[b] = (float)(fx0 + b);
-            const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
-            if (!(p.debugSkip & 2u))
-                rasterRegion<true, 0>(lds.planes, act, 0, px, py, invNear, best[g], bid[g]);
-            // shade this chunk's winners before its records are replaced
+            // lane k looks at the region mask of records k, 64 + k, ...; draw
+            // order is record order, so the sub-chunks are visited in order
+            for (int sub = 0; sub < subs; ++sub) {
+                const uint32_t mask = __float_as_uint(lds.planes[sub * kWave + lane][12]);
+                const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
+                if (!(p.debugSkip & 2u))
+                    rasterRegion<true, 0>(lds.planes, act, sub * kWave, px, py, invNear, best[g], bid[g]);
+            }
+            // shade this pass's winners before its records are replaced
 #pragma unroll
             for (int b = 0; b < kRegionBlocks; ++b) {
                 if (bid[g][b] >= 0)
