@@ -197,6 +197,26 @@ def test_more_than_64_triangles_per_world_uses_chunks(native):
     assert got["tri_id"].max() >= 64
 
 
+@pytest.mark.parametrize("cubes", [21, 25, 44, 70])
+def test_several_passes_of_256_triangles(native, cubes):
+    # 254 / 302 / 530 / 842 triangles: a pass that is exactly short of full, a
+    # second pass with one sub-chunk, three and four passes; textured cubes so
+    # that winners of an early pass are shaded before their records are replaced
+    rng = np.random.default_rng(cubes)
+    inst = [((0.0, 0.0, 0.0), IDENT, (1.0, 1.0, 1.0), 1)]
+    for _ in range(cubes):
+        p = rng.uniform(-7, 7, 3)
+        s = float(rng.uniform(0.4, 1.3))
+        inst.append(((float(p[0]), float(p[1]), float(abs(p[2]) * 0.3)), IDENT, (s, s, s), 0))
+    cams = [((13.0, -10.0, 8.0), scenes.look_at((13.0, -10.0, 8.0), (0, 0, 0.5))),
+            ((-2.0, 15.0, 2.5), scenes.look_at((-2.0, 15.0, 2.5), (0, 0, 0.5)))]
+    d = _world(inst, [(CUBE, 0), (PLANE, 1)], cams,
+               materials=[((0.9, 0.7, 0.5, 1.0), 0, 0.5, 0.5), ((0.3, 0.6, 0.3, 1.0), -1, 0.5, 0.5)],
+               texture_paths=[os.path.join(scenes.DATA_DIR, "cube.png")], width=96, height=72)
+    _, got, _ = _parity(d)
+    assert got["tri_id"].max() >= min(256, 10 * cubes)        # later passes own pixels too
+
+
 def test_edge_cases_empty_worlds_bad_ids_degenerate_triangles(native):
     verts = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0],        # collinear: zero area
                       [0, 0, 0], [1, 0, 0], [0, 0, 1]], np.float32)
