@@ -818,33 +818,36 @@ void rasterChunkedKernel(const RasterParams p)
 //   R+O all waves pull (tile, strip) items off an LDS counter, rasterise the
 //       strip's two regions and store them.
 // ---------------------------------------------------------------------------
-// A group is up to kGroupTilesMax tiles drawn from one or more views whose
-// triangles fit kChunk records together (setup is per view, shared by the
-// view's tiles); with the XCD-aware split a workgroup on a fast XCD carries
-// one 16-slot view more.
-constexpr int kGroupRecs = kChunk + 16;
+// A group is up to 16 tiles drawn from one or more views whose triangles fit
+// the records together (setup is per view, shared by the view's tiles).  Up to
+// 64 slots per view the group holds kChunk records (with the XCD-aware split
+// a workgroup on a fast XCD carries one 16-slot view more); views of 128 / 256
+// slots are one view per group.
 constexpr int kGroupTilesMax = 16;
-constexpr int kBackground = kGroupRecs;   // record index of "nothing hit"
+constexpr int kGroupSlotsMax = 256;
+constexpr int groupTilesMax(int slots) { return slots <= 128 ? kGroupTilesMax : 8; }
 
+template <int SLOTS>
 struct GroupLds {
-    float planes[kGroupRecs][16];       // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | bbox
-    uint32_t live[kGroupRecs];          // record holds a triangle that can be visible
-    float shade[kGroupRecs + 1][4];     // rgba, texture, objectID, world-local index
-    float cold[kGroupRecs][kCold];      // u/v planes, lit colour
+    static constexpr int kRecs = SLOTS <= kChunk ? kChunk + 16 : SLOTS;
+    static constexpr int kBackground = kRecs;   // record index of "nothing hit"
+    float planes[kRecs][16];            // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | bbox
+    uint32_t live[kRecs];               // record holds a triangle that can be visible
+    float shade[kRecs + 1][4];          // rgba, texture, objectID, world-local index
+    float cold[kRecs][kCold];           // u/v planes, lit colour
     // per (tile, slot of the tile's view): region bits 0..15, near-free bits 16..19
-    uint32_t masks[kGroupTilesMax * kChunk];
+    uint32_t masks[groupTilesMax(SLOTS) * (SLOTS <= kChunk ? kChunk : SLOTS)];
     uint32_t tileInfo[kGroupTilesMax][4];   // view, x0, y0, flags | first record << 8
     uint32_t nextItem;                  // (tile, strip) work counter of phase R
 };
 constexpr uint32_t kTileValid = 4u;
 
-__device__ __forceinline__ const float *shadeRec(const GroupLds &L, int32_t w) { return L.shade[w]; }
 
 // Shade + store one region of a tile (group kernel).  `bid` is the byte offset
 // of the winner's shading record (the background has its own record, so the
 // lookup is unconditional); base pointers are wave-uniform.
-template <bool IDS, bool FULL, bool TEX>
-__device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLds &L,
+template <bool IDS, bool FULL, bool TEX, typename LDS>
+__device__ __forceinline__ void storeRegion(const RasterParams &p, const LDS &L,
                                             uint32_t *rgbTile, float *depthTile, int32_t *idsTile,
                                             uint32_t pixOff, uint32_t fx0, uint32_t fy,
                                             bool anyTex, const float (&px)[kRegionBlocks], float py,
@@ -863,7 +866,7 @@ __device__ __forceinline__ void storeRegion(const RasterParams &p, const GroupLd
             id[b] = __float_as_int(p.idsAreSegmask ? h[2] : h[3]);
         // depth = 1/best: v_rcp_f32 (<= 1 ulp); textured colour below uses the
         // correctly rounded quotient because texel choice depends on it
-        dep[b] = bid[b] != kBackground * 16 ? __builtin_amdgcn_rcpf(best[b]) : 0.0f;
+        dep[b] = bid[b] != LDS::kBackground * 16 ? __builtin_amdgcn_rcpf(best[b]) : 0.0f;
     }
     // TEX is a kernel-level switch: texel loads inside the work loop make the
     // compiler drain vmcnt at every loop header, which would also wait for the
@@ -931,10 +934,12 @@ __device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t 
 constexpr int groupWaves(bool tex) { return tex ? 4 : 8; }
 
 template <bool IDS, int SLOTS, bool TEX>
-__global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? 4 : 8)
+// (the second bound is waves per SIMD; 256-slot groups are LDS-limited to 3 per CU)
+__global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? (SLOTS > 128 ? 3 : 4) : (SLOTS > 128 ? 6 : 8))
 void rasterGroupKernel(const RasterParams p)
 {
-    __shared__ GroupLds lds;
+    __shared__ GroupLds<SLOTS> lds;
+    constexpr int kBackground = GroupLds<SLOTS>::kBackground;
     // readfirstlane: the compiler cannot see that threadIdx.x / 64 is
     // wave-uniform and would predicate every `wave` branch instead of jumping
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -988,7 +993,21 @@ void rasterGroupKernel(const RasterParams p)
         lds.masks[i] = 0u;
 
     // ---- S1: one lane per (view vi of the group, triangle slot k): setup.
-    //      Wave 0 covers the first 64 records, wave 1 a fifth 16-slot view.
+    //      Wave 0 covers the first 64 records, wave 1 a fifth 16-slot view or
+    //      the next 64 slots of a large view, ...  Meanwhile the last wave
+    //      notes where each tile of the group lies.
+    if (wave == groupWaves(TEX) - 1 && lane < (int)groupTiles) {
+        uint32_t vi = (uint32_t)lane, tile = firstTile;
+        if (tilesPerView != 1) {
+            vi = groupViews == 1 ? 0u : (uint32_t)lane / tilesPerView;
+            tile = firstTile + (uint32_t)lane - vi * tilesPerView;
+        }
+        const uint32_t ty = tilesPerView != 1 ? tile / p.tilesFast : 0u;
+        lds.tileInfo[lane][0] = firstView + vi;
+        lds.tileInfo[lane][1] = (tile - ty * p.tilesFast) * 64u;
+        lds.tileInfo[lane][2] = ty * 64u;
+        lds.tileInfo[lane][3] = (firstView + vi < p.numViews ? kTileValid : 0u) | ((vi * SLOTS) << 8);
+    }
     if (wave * kWave < groupRecs) {
         const int rec = wave * kWave + lane;
         const int vi = rec / SLOTS, k = rec % SLOTS;
@@ -1061,20 +1080,6 @@ void rasterGroupKernel(const RasterParams p)
             lds.shade[kBackground][2] = __int_as_float(-1);
             lds.shade[kBackground][3] = __int_as_float(-1);
         }
-    } else if (wave == 3) {
-        // meanwhile: where each tile of the group lies
-        if (lane < (int)groupTiles) {
-            uint32_t vi = (uint32_t)lane, tile = firstTile;
-            if (tilesPerView != 1) {
-                vi = groupViews == 1 ? 0u : (uint32_t)lane / tilesPerView;
-                tile = firstTile + (uint32_t)lane - vi * tilesPerView;
-            }
-            const uint32_t ty = tilesPerView != 1 ? tile / p.tilesFast : 0u;
-            lds.tileInfo[lane][0] = firstView + vi;
-            lds.tileInfo[lane][1] = (tile - ty * p.tilesFast) * 64u;
-            lds.tileInfo[lane][2] = ty * 64u;
-            lds.tileInfo[lane][3] = (firstView + vi < p.numViews ? kTileValid : 0u) | ((vi * SLOTS) << 8);
-        }
     }
     __syncthreads();
     MRX_STAMP(3);
@@ -1125,7 +1130,9 @@ void rasterGroupKernel(const RasterParams p)
     const int lx = lane & 7, ly = lane >> 3;
     const uint32_t laneOff = (uint32_t)ly * p.nfast + 4u * lx;
     int cachedTile = -1, recBase = 0;
-    uint32_t view = 0, tileX0 = 0, tileY0 = 0, mask = 0;
+    constexpr int SUBS = (SLOTS + kWave - 1) / kWave;     // 64-slot sub-chunks of a view
+    constexpr int LANES = SLOTS < kWave ? SLOTS : kWave;
+    uint32_t view = 0, tileX0 = 0, tileY0 = 0, mask[SUBS] = {};
     float pxTile[2][kRegionBlocks] = {};
     bool anyTex = false, nearFree = false, full = false;
     uint32_t *rgbTile = nullptr;
@@ -1154,13 +1161,20 @@ void rasterGroupKernel(const RasterParams p)
             depthTile = p.depth + tileBase;
             idsTile = IDS ? p.ids + tileBase : nullptr;
             full = (p.nfast & 3u) == 0 && tileX0 + 64u <= p.nfast && tileY0 + 64u <= p.nslow;
-            // lane k < SLOTS looks at the region mask of triangle slot k of tile j
-            mask = lane < SLOTS ? lds.masks[j * SLOTS + lane] : 0u;
-            const int32_t tex = lane < SLOTS ? __float_as_int(lds.shade[recBase + lane][1]) : -1;
-            anyTex = __ballot((mask & 0xFFFFu) != 0 && tex >= 0) != 0;
-            // every surviving triangle stays behind the near plane over the
-            // whole tile: the per-pixel near test is dropped for the tile
-            nearFree = __ballot((mask & 0xFFFFu) != 0 && ((mask >> 16) & 0xFu) != 0xFu) == 0;
+            // lane k looks at the region masks of triangle slots k, 64 + k, ... of tile j
+            anyTex = false;
+            nearFree = true;
+#pragma unroll
+            for (int sub = 0; sub < SUBS; ++sub) {
+                const int slot = sub * kWave + lane;
+                mask[sub] = lane < LANES ? lds.masks[j * SLOTS + slot] : 0u;
+                const int32_t tex = lane < LANES ? __float_as_int(lds.shade[recBase + slot][1]) : -1;
+                anyTex = anyTex || __ballot((mask[sub] & 0xFFFFu) != 0 && tex >= 0) != 0;
+                // every surviving triangle stays behind the near plane over the
+                // whole tile: the per-pixel near test is dropped for the tile
+                nearFree = nearFree &&
+                           __ballot((mask[sub] & 0xFFFFu) != 0 && ((mask[sub] >> 16) & 0xFu) != 0xFu) == 0;
+            }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -1173,9 +1187,15 @@ void rasterGroupKernel(const RasterParams p)
         for (int hf = 0; hf < 2; ++hf) {
             const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
             const uint32_t pixOff = (uint32_t)(strip * 8) * p.nfast + hf * 32 + laneOff;
-            // bit k: triangle slot k of the tile's view survives in this region
-            const uint64_t act = __ballot((mask >> (2 * strip + hf)) & 1u);
-            if (act == 0) {
+            // bit k of act[sub]: triangle slot 64 sub + k of the tile's view survives here
+            uint64_t act[SUBS];
+            bool any = false;
+#pragma unroll
+            for (int sub = 0; sub < SUBS; ++sub) {
+                act[sub] = __ballot((mask[sub] >> (2 * strip + hf)) & 1u);
+                any = any || act[sub] != 0;
+            }
+            if (!any) {
                 if (full)
                     storeBackground<IDS, true>(p, rgbTile, depthTile, idsTile, pixOff, fx0, fy);
                 else
@@ -1191,10 +1211,15 @@ void rasterGroupKernel(const RasterParams p)
                 bid[b] = kBackground * 16;
             }
             if (!(p.debugSkip & 2u)) {
-                if (nearFree)
-                    rasterRegion<false, 4>(lds.planes, act, recBase, px, py, invNear, best, bid);
-                else
-                    rasterRegion<true, 4>(lds.planes, act, recBase, px, py, invNear, best, bid);
+#pragma unroll
+                for (int sub = 0; sub < SUBS; ++sub) {
+                    if (SUBS > 1 && act[sub] == 0)
+                        continue;
+                    if (nearFree)
+                        rasterRegion<false, 4>(lds.planes, act[sub], recBase + sub * kWave, px, py, invNear, best, bid);
+                    else
+                        rasterRegion<true, 4>(lds.planes, act[sub], recBase + sub * kWave, px, py, invNear, best, bid);
+                }
             }
             if (full)
                 storeRegion<IDS, true, TEX>(p, lds, rgbTile, depthTile, idsTile, pixOff, fx0, fy,
@@ -1222,7 +1247,8 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
     const bool ids = p.ids != nullptr;
-    const bool multi = maxWorldTris > (uint32_t)kChunk;
+    const bool multi = maxWorldTris > (uint32_t)kChunk;       // brute variant: chunk loop
+    const bool large = maxWorldTris > (uint32_t)kGroupSlotsMax;
     if (variant == kVariantBrute) {
         // v1 reference: one wave per tile, every triangle at every pixel
         const dim3 grid((items + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -1233,39 +1259,42 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
             if (multi) rasterBruteKernel<false, true><<<grid, block, 0, stream>>>(p);
             else       rasterBruteKernel<false, false><<<grid, block, 0, stream>>>(p);
         }
-    } else if (multi) {
-        // more than one chunk of triangles per world: one workgroup per tile
+    } else if (large) {
+        // more triangles per world than the group kernel holds: one workgroup per tile
         if (ids) rasterChunkedKernel<true><<<dim3(items), block, 0, stream>>>(p);
         else     rasterChunkedKernel<false><<<dim3(items), block, 0, stream>>>(p);
     } else {
-        // triangle slots per view: the smallest of 16 / 32 / 64 that holds a world
-        int slots = maxWorldTris <= 16 ? 16 : maxWorldTris <= 32 ? 32 : 64;
-        if (p.debugSlots >= slots && (p.debugSlots == 32 || p.debugSlots == 64))
-            slots = p.debugSlots;                 // tuning aid (MRX_DEBUG_SLOTS)
+        // triangle slots per view: the smallest of 16 ... 256 that holds a world
+        int slots = 16;
+        while ((uint32_t)slots < maxWorldTris)
+            slots *= 2;
+        if (p.debugSlots >= slots && p.debugSlots <= kGroupSlotsMax && (p.debugSlots & (p.debugSlots - 1)) == 0)
+            slots = p.debugSlots;                 // tuning / test aid (MRX_DEBUG_SLOTS)
         // Workgroup shape.  Setup is per view and the view's tiles share it, so
-        // a workgroup takes as many whole views as fit 64 records and 16 tiles;
-        // a view of more than 16 tiles is cut into chunks of 16.  Small batches
-        // shrink the workgroups again until there are ~4 per CU.
+        // a workgroup takes as many whole views as fit 64 records and 16 tiles
+        // (8 for views of 256 slots); a view of more tiles is cut into chunks.
+        // Small batches shrink the workgroups again until there are ~4 per CU.
         const uint32_t tpv = p.tilesFast * p.tilesSlow;
+        const uint32_t maxTiles = (uint32_t)groupTilesMax(slots);
         constexpr uint32_t kFill = 1024;          // 256 CUs x 4 resident workgroups
         RasterParams q = p;
         uint32_t vg = 1, ct = tpv, gpv = 1;
-        if (tpv <= (uint32_t)kGroupTilesMax) {
-            vg = std::min<uint32_t>((uint32_t)(kChunk / slots), (uint32_t)kGroupTilesMax / tpv);
+        if (tpv <= maxTiles) {
+            vg = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)(kChunk / slots), maxTiles / tpv));
             while (vg > 1 && (p.numViews + vg - 1) / vg < kFill)
                 vg /= 2;
         } else {
-            ct = (uint32_t)kGroupTilesMax;
+            ct = maxTiles;
         }
         if (vg == 1)
             while (ct > 1 && (uint64_t)p.numViews * ((tpv + ct - 1) / ct) < kFill)
                 ct = (ct + 1) / 2;
-        if (p.grpViewsWanted > 0 && tpv * (uint32_t)p.grpViewsWanted <= (uint32_t)kGroupTilesMax &&
+        if (p.grpViewsWanted > 0 && tpv * (uint32_t)p.grpViewsWanted <= maxTiles &&
             p.grpViewsWanted * slots <= kChunk) {
             vg = (uint32_t)p.grpViewsWanted;
             ct = tpv;
         }
-        if (p.grpTilesWanted > 0 && p.grpTilesWanted <= kGroupTilesMax) {
+        if (p.grpTilesWanted > 0 && (uint32_t)p.grpTilesWanted <= maxTiles) {
             vg = 1;
             ct = std::min<uint32_t>((uint32_t)p.grpTilesWanted, tpv);
         }
@@ -1297,7 +1326,9 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
     } while (0)
         if (slots == 16) MRX_GROUP(16);
         else if (slots == 32) MRX_GROUP(32);
-        else MRX_GROUP(64);
+        else if (slots == 64) MRX_GROUP(64);
+        else if (slots == 128) MRX_GROUP(128);
+        else MRX_GROUP(256);
 #undef MRX_GROUP
     }
     return hipGetLastError();

@@ -88,6 +88,19 @@ def test_workgroup_shapes(native, monkeypatch, kw, env):
     _parity(scenes.synthetic_scene(**kw))
 
 
+@pytest.mark.parametrize("slots", [32, 64, 128, 256])
+@pytest.mark.parametrize("kw", [
+    dict(num_worlds=6, with_wall=True, textured=True),
+    dict(num_worlds=3, width=200, height=136, with_wall=True),
+    dict(num_worlds=2, width=320, height=256, textured=True, render_mode="Raytracer"),
+], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_more_triangle_slots_than_needed(native, monkeypatch, kw, slots):
+    # the 128- and 256-slot instantiations (several setup waves, several 64-slot
+    # sub-chunks per region) on scenes whose answer is known from the small ones
+    monkeypatch.setenv("MRX_DEBUG_SLOTS", str(slots))
+    _parity(scenes.synthetic_scene(**kw))
+
+
 def test_write_back_store_policy_gives_the_same_bytes(native, monkeypatch):
     desc = scenes.synthetic_scene(num_worlds=40, with_wall=True, textured=True)
     _, a, _ = _parity(desc)
