@@ -839,6 +839,7 @@ struct GroupLds {
     uint32_t masks[groupTilesMax(SLOTS) * (SLOTS <= kChunk ? kChunk : SLOTS)];
     uint32_t tileInfo[kGroupTilesMax][4];   // view, x0, y0, flags | first record << 8
     uint32_t nextItem;                  // (tile, strip) work counter of phase R
+    uint8_t itemOrder[kGroupTilesMax * 8];  // work item -> tile * 8 + strip
 };
 constexpr uint32_t kTileValid = 4u;
 
@@ -1008,6 +1009,27 @@ void rasterGroupKernel(const RasterParams p)
         lds.tileInfo[lane][2] = ty * 64u;
         lds.tileInfo[lane][3] = (firstView + vi < p.numViews ? kTileValid : 0u) | ((vi * SLOTS) << 8);
     }
+    // ... and the order of the work items.  One-tile views: strip by strip
+    // across the views, top strips first -- strips above the horizon cost
+    // nothing, so every wave has stores in flight right after the barrier.
+    // Larger views: tile by tile (switching tiles per item costs more there).
+    if (wave == groupWaves(TEX) - 1) {
+        uint32_t base = 0;
+        for (uint32_t c0 = 0; c0 < groupTiles * 8u; c0 += kWave) {
+            const uint32_t c = c0 + (uint32_t)lane;
+            uint32_t strip = c / groupTiles, tile = c - strip * groupTiles;
+            if (tilesPerView != 1) {
+                tile = c >> 3;
+                strip = c & 7u;
+            }
+            const uint32_t g = tile * 8u + strip;
+            const bool ok = strip < 8u && g >= firstStrip && g < firstStrip + numStrips;
+            const uint64_t m = __ballot(ok);
+            if (ok)
+                lds.itemOrder[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)g;
+            base += (uint32_t)__builtin_popcountll(m);
+        }
+    }
     if (wave * kWave < groupRecs) {
         const int rec = wave * kWave + lane;
         const int vi = rec / SLOTS, k = rec % SLOTS;
@@ -1145,7 +1167,7 @@ void rasterGroupKernel(const RasterParams p)
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= numStrips)
             break;
-        item += firstStrip;
+        item = __builtin_amdgcn_readfirstlane((uint32_t)lds.itemOrder[item]);
         const int j = (int)(item >> 3), strip = (int)(item & 7u);
         if (j != cachedTile) {
             cachedTile = j;
