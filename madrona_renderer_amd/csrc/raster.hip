@@ -1170,10 +1170,10 @@ void rasterGroupKernel(const RasterParams p)
         item = __builtin_amdgcn_readfirstlane((uint32_t)lds.itemOrder[item]);
         const int j = (int)(item >> 3), strip = (int)(item & 7u);
         if (j != cachedTile) {
-            cachedTile = j;
             const uint32_t info = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][3]);
             if (!(info & kTileValid))
-                break;                              // views past the end of the batch
+                continue;                           // a view past the end of the batch
+            cachedTile = j;
             recBase = (int)(info >> 8);
             view = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][0]);
             tileX0 = __builtin_amdgcn_readfirstlane(lds.tileInfo[j][1]);
@@ -1330,8 +1330,8 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         // profiles/r01_xcd.txt): once the batch fills the chip, xcdSkew strips
         // (eighths of a tile) per workgroup pair move from the odd to the even
         // XCD (see the kernel prologue).
-        const bool skewable = slots == 16 && tpv == 1 && vg == 4;
-        q.xcdSkew = (skewable && numGroups >= kFill) ? 3u : 0u;
+        const bool skewable = slots == 16 && tpv == 1 && (vg == 4 || vg == 2);
+        q.xcdSkew = (skewable && numGroups >= kFill) ? (vg == 4 ? 3u : 1u) : 0u;
         if (p.xcdSkewWanted >= 0)
             q.xcdSkew = skewable ? (uint32_t)(p.xcdSkewWanted < 8 ? p.xcdSkewWanted : 7) : 0u;
         const dim3 grid(numGroups);

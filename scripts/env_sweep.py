@@ -9,6 +9,7 @@ import torch
 from madrona_renderer_amd import scenes
 
 CONFIGS = {
+    "C4": dict(num_worlds=2048),
     "C2": dict(num_worlds=1024),
     "C3": dict(num_worlds=4096, width=128, height=128, with_wall=True),
     "C5": dict(num_worlds=4096, width=256, height=256, textured=True, render_mode="Raytracer"),

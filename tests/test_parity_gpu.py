@@ -53,20 +53,29 @@ def test_synthetic_scenes(native, kw):
     _parity(scenes.synthetic_scene(**kw))
 
 
-@pytest.mark.parametrize("strips", [1, 3, 7])
+@pytest.mark.parametrize("views,strips", [(4, 0), (4, 1), (4, 3), (4, 7), (2, 0), (2, 1), (2, 5)])
 @pytest.mark.parametrize("kw", [
     dict(num_worlds=64),
     dict(num_worlds=7),                                  # odd workgroup count: unpaired last group
     dict(num_worlds=9, textured=True),                   # four-wave variant, second classify pass
-    dict(num_worlds=5, width=96, height=40),             # pairs straddle views, ragged tiles
-    dict(num_worlds=3, width=130, height=70, render_mode="Raytracer"),
+    dict(num_worlds=13, render_mode="Raytracer"),        # transposed storage, segmask
 ], ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
-def test_xcd_aware_split_forced_on_small_batches(native, monkeypatch, kw, strips):
+def test_xcd_aware_split_forced_on_small_batches(native, monkeypatch, kw, views, strips):
     # the split that moves strips between the workgroups of a pair (odd -> even
-    # XCD) normally starts at 4096 tiles; force it so that small, ragged batches
-    # exercise the five-tile workgroups as well
+    # XCD) normally starts at 1024 groups of 4 (or 2) one-tile views; force the
+    # group size and the split so that small, ragged batches exercise the
+    # workgroups that carry an extra view
+    monkeypatch.setenv("MRX_GROUP_VIEWS", str(views))
     monkeypatch.setenv("MRX_XCD_SKEW", str(strips))
     _parity(scenes.synthetic_scene(**kw))
+
+
+def test_2048_worlds_use_the_split_with_two_views_per_group(native):
+    desc = scenes.synthetic_scene(2048)
+    r = make_product(desc, visibility=False)
+    got = fetch(r, visibility=False)
+    ref = render_oracle(desc, want_ids=False)
+    assert_parity(got, ref)
 
 
 @pytest.mark.parametrize("env", [
