@@ -78,6 +78,35 @@ def test_random_raw_geometry_scenes(native, seed, size, mode):
     assert (ref["tri_id"] >= 0).mean() > 0.01          # the scenes do draw something
 
 
+@pytest.mark.parametrize("seed", range(20, 36))
+def test_random_scenes_under_random_kernel_shapes(native, monkeypatch, seed):
+    # the same kind of scene under a random choice of the knobs that select the
+    # kernel instantiation and the workgroup shape (none may change a byte):
+    # triangle slots, whole views / tiles per workgroup, XCD split, store policy,
+    # with or without the id tensor
+    rng = np.random.default_rng(1000 + seed)
+    w, h = [(64, 64), (64, 64), (128, 64), (96, 130), (33, 64), (256, 192)][int(rng.integers(0, 6))]
+    mode = "Raytracer" if rng.integers(0, 3) == 0 else "Rasterizer"
+    if mode == "Raytracer":
+        h = w
+    d = _scene(seed, num_worlds=int(rng.integers(5, 41)), width=w, height=h, mode=mode)
+    env = {"MRX_DEBUG_SLOTS": str([16, 32, 64, 128, 256][int(rng.integers(0, 5))])}
+    if rng.integers(0, 2):
+        env["MRX_GROUP_VIEWS"] = str([1, 2, 4][int(rng.integers(0, 3))])
+        env["MRX_XCD_SKEW"] = str(int(rng.integers(0, 8)))
+    else:
+        env["MRX_GROUP_TILES"] = str(int(rng.integers(1, 17)))
+    if rng.integers(0, 4) == 0:
+        env["MRX_WRITE_THROUGH"] = "0"
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ids = bool(rng.integers(0, 2))
+    r = make_product(d, visibility=ids)
+    got = fetch(r, visibility=ids, raytracer=(mode == "Raytracer"))
+    ref = render_oracle(d)
+    assert_parity(got, ref)
+
+
 def test_random_scene_on_brute_variant_too(native):
     d = _scene(11, num_worlds=16, width=64, height=64, mode="Rasterizer")
     r = make_product(d, visibility=True, variant=1)
