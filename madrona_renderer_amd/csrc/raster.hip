@@ -1,11 +1,12 @@
 // Tiled software rasterizer / primary-ray caster for gfx950 (MI355X).
 //
 // Three kernels share the spec arithmetic below:
-//   rasterGroupKernel    the production path for worlds of <= 64 triangles:
-//                        one workgroup per group of tiles, dense setup,
-//                        register/LDS binning, packed-FMA raster, 16-byte stores
-//   rasterChunkedKernel  worlds of more than 64 triangles: one workgroup per
-//                        tile, triangles through LDS in chunks of 64
+//   rasterGroupKernel    the production path for worlds of <= 256 triangles:
+//                        one workgroup per group of views / tiles, setup per
+//                        view, register/LDS binning, packed-FMA raster,
+//                        16-byte write-through stores
+//   rasterChunkedKernel  worlds of more than 256 triangles: one workgroup per
+//                        tile, triangles through LDS in passes of 256
 //   rasterBruteKernel    the round's first kernel (every triangle at every
 //                        pixel), kept as an on-device cross-check (variant 1)
 // Phases: S setup (lane = triangle: pose -> view-space vertices -> edge /
@@ -808,13 +809,14 @@ void rasterChunkedKernel(const RasterParams p)
 }
 
 // ---------------------------------------------------------------------------
-// Worlds of at most 64 triangles (every BASELINE scene): one workgroup renders
-// a group of G = 64 / SLOTS consecutive tiles.
-//   S1  wave 0 sets up the triangles of all G tiles in ONE pass (lane = tile
-//       j, triangle slot k: dense lanes instead of 14-of-64) and publishes
-//       planes, bounding boxes and shading records in LDS;
-//   S2  waves 0-3 each classify four of the sixteen regions of every
-//       triangle (lane = the same (j, k)), OR-ing the bits into LDS;
+// Worlds of at most 256 triangles (every BASELINE scene): one workgroup renders
+// a group of views (all their tiles) or a chunk of the tiles of one view.
+//   S1  one lane per (view of the group, triangle slot): the setup waves
+//       publish planes, bounding boxes and shading records in LDS (dense
+//       lanes: four 14-triangle views fill 56 of wave 0's 64 lanes); the last
+//       wave notes where the group's tiles lie and the order of the work items;
+//   S2  one lane per (tile, triangle slot): wave w classifies four of the
+//       tile's sixteen regions (strips 2(w&3), 2(w&3)+1), OR-ing bits into LDS;
 //   R+O all waves pull (tile, strip) items off an LDS counter, rasterise the
 //       strip's two regions and store them.
 // ---------------------------------------------------------------------------
