@@ -51,12 +51,12 @@ struct DevBuf {
     size_t count = 0;
     bool owned = true;
     void *base = nullptr;                       // what hipMalloc returned (ptr may sit inside it)
-    hipError_t alloc(size_t n, size_t skewBytes = 0)
+    hipError_t alloc(size_t n, size_t tailBytes = 0)     // tail: room for slices (view) behind the data
     {
         count = n;
         owned = true;
-        const hipError_t e = hipMalloc(&base, (n ? n : 1) * sizeof(T) + skewBytes);
-        ptr = e == hipSuccess ? reinterpret_cast<T *>(static_cast<char *>(base) + skewBytes) : nullptr;
+        const hipError_t e = hipMalloc(&base, (n ? n : 1) * sizeof(T) + tailBytes);
+        ptr = e == hipSuccess ? static_cast<T *>(base) : nullptr;
         return e;
     }
     void view(void *base, size_t n)             // a slice of another allocation (not owned)
@@ -82,23 +82,37 @@ struct DevBuf {
     }
 };
 
-// A lane stores the same pixels of every output tensor back to back.  The
-// allocations are 2 MiB-aligned, and when two tensors lie a multiple of 512
-// KiB apart those stores collide in the memory system (measured: a 64 MiB +
-// 64 MiB render takes 24.1 us at distance = 0 mod 512 KiB and 22.5 us at 256
-// KiB mod 512 KiB, profiles/r01_placement.txt) -- so the depth and id tensors
-// start a fraction of that period into their allocations.
-size_t outSkewDepth()
+// The output tensors of a renderer live in ONE allocation, rgb first.  A lane
+// stores the same pixels of every tensor back to back, and when two tensors
+// lie a multiple of 512 KiB apart those stores collide in the memory system
+// (measured: a 64 MiB + 64 MiB render takes 24.1 us at distance = 0 mod 512 KiB
+// and 22.5 us at 256 KiB mod 512 KiB, profiles/r01_placement.txt).  Separate
+// hipMalloc blocks are 2 MiB-aligned -- the bad case -- and their physical
+// distance is anybody's guess; inside one allocation the distance is ours:
+// depth starts at phase 256 KiB of the 512 KiB period, ids at phase 64 KiB.
+constexpr size_t kOutPeriod = 512u << 10;
+size_t outPhase(const char *env, size_t dflt)
 {
-    if (const char *dbg = std::getenv("MRX_OUT_SKEW_DEPTH_KB"))
+    if (const char *dbg = std::getenv(env))
         return (size_t)std::atoll(dbg) << 10;
-    return 256u << 10;
+    return dflt;
 }
-size_t outSkewIds()
+hipError_t allocOutputs(size_t px, bool wantIds, DevBuf<uint32_t> &rgb, DevBuf<float> &depth,
+                        DevBuf<int32_t> &ids)
 {
-    if (const char *dbg = std::getenv("MRX_OUT_SKEW_IDS_KB"))
-        return (size_t)std::atoll(dbg) << 10;
-    return 128u << 10;
+    const size_t tb = (px * 4 + kOutPeriod - 1) / kOutPeriod * kOutPeriod;
+    const size_t depthOff = tb + outPhase("MRX_OUT_SKEW_DEPTH_KB", 256u << 10);
+    const size_t idsOff = depthOff + tb + kOutPeriod - (depthOff % kOutPeriod) +
+                          outPhase("MRX_OUT_SKEW_IDS_KB", 64u << 10);
+    const size_t total = (wantIds ? idsOff : depthOff) + px * 4;
+    const hipError_t e = rgb.alloc(px, total - px * 4);
+    if (e != hipSuccess)
+        return e;
+    char *base = static_cast<char *>(rgb.base);
+    depth.view(base + depthOff, px);
+    if (wantIds)
+        ids.view(base + idsOff, px);
+    return hipSuccess;
 }
 
 }  // namespace
@@ -426,11 +440,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // image y (callers read it as [x][y]: scripts/test.py:160, dump.cpp:9-21)
     const uint32_t nfast = rt ? H : W, nslow = rt ? W : H;
     const size_t px = (size_t)nviews * nfast * nslow;
-    MRX_HIP(r.rgb.alloc(px));
-    MRX_HIP(r.depth.alloc(px, outSkewDepth()));
+    MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), r.rgb, r.depth, r.ids));
     const bool wantIds = rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS);
-    if (wantIds)
-        MRX_HIP(r.ids.alloc(px, outSkewIds()));
 
     RasterParams &p = r.params;
     p.tris = r.tris.ptr;
@@ -643,10 +654,8 @@ static int choosePlacement(mrx_renderer *r)
         else
             (void)hipGetLastError();
         Cand c;
-        if (c.rgb.alloc(px) != hipSuccess || c.depth.alloc(px, outSkewDepth()) != hipSuccess ||
-            (wantIds && c.ids.alloc(px, outSkewIds()) != hipSuccess)) {
+        if (allocOutputs(px, wantIds, c.rgb, c.depth, c.ids) != hipSuccess) {
             (void)hipGetLastError();                  // out of memory: make do with what there is
-            c.rgb.release(); c.depth.release(); c.ids.release();
             break;
         }
         cand.push_back(c);
