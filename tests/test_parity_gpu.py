@@ -119,6 +119,31 @@ def test_write_back_store_policy_gives_the_same_bytes(native, monkeypatch):
         assert np.array_equal(a[k], b[k])
 
 
+def test_output_placement_search_changes_no_byte_and_pointers_stay_put(native, monkeypatch):
+    # mrx_create times candidate allocations of the output tensors and keeps the
+    # fastest; whatever it picks, the tensors hold the same bytes, do not overlap
+    # and do not move afterwards
+    desc = scenes.synthetic_scene(num_worlds=300, textured=True, render_mode="Raytracer")
+    monkeypatch.setenv("MRX_PLACEMENT_TRIES", "1")
+    _, a, _ = _parity(desc)
+    monkeypatch.setenv("MRX_PLACEMENT_TRIES", "5")
+    monkeypatch.setenv("MRX_OUT_SKEW_DEPTH_KB", "0")
+    r, b, _ = _parity(desc)
+    for k in ("rgb", "depth", "tri_id"):
+        assert np.array_equal(a[k], b[k])
+    def ptrs():
+        return [r.rgb_cuda_ptr(), r.depth_cuda_ptr(), r.visibility_tensor().to_torch().data_ptr()]
+    before = ptrs()
+    nbytes = 300 * 64 * 64 * 4
+    spans = sorted((p, p + nbytes) for p in before)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(2))
+    for _ in range(3):
+        r.step()
+    r.sync()
+    assert before == ptrs()
+    assert r.rgb_tensor().to_torch().data_ptr() == before[0]
+
+
 def test_headline_config_full_size(native):
     # BASELINE north star: 4096 worlds x 64x64 -- every pixel of every view
     desc = scenes.synthetic_scene(4096)
