@@ -540,6 +540,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         p.grpViewsWanted = std::atoi(dbg);
     if (const char *dbg = std::getenv("MRX_GROUP_TILES"))
         p.grpTilesWanted = std::atoi(dbg);
+    p.xcdRotate = 0;
+    p.xcdRotateWanted = -1;
+    if (const char *dbg = std::getenv("MRX_XCD_ROTATE"))
+        p.xcdRotateWanted = std::atoi(dbg);
     p.xcdSkew = 0;
     p.xcdSkewWanted = -1;
     if (const char *dbg = std::getenv("MRX_XCD_SKEW"))

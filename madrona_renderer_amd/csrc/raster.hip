@@ -952,15 +952,22 @@ void rasterGroupKernel(const RasterParams p)
     //  A  grpPerView == 1: grpViews whole views (all their tiles);
     //  B  otherwise: grpChunkTiles tiles of one view.
     uint32_t firstView, groupViews, firstTile, groupTiles;
+    // Workgroup b runs on XCD b % 8.  With xcdRotate the group it renders moves
+    // two places on within its round of eight, round after round, so that an
+    // XCD does not keep writing the same eighth of every 512 KiB of the output
+    // (parity is kept: the XCD-aware split below pairs even with odd groups).
+    uint32_t bid = blockIdx.x;
+    if (p.xcdRotate && (bid | 7u) < gridDim.x)
+        bid = (bid & ~7u) | ((bid + 2u * (bid >> 3)) & 7u);
     if (p.grpPerView == 1) {
-        firstView = blockIdx.x * p.grpViews;
+        firstView = bid * p.grpViews;
         groupViews = p.grpViews;
         firstTile = 0;
         groupTiles = groupViews * tilesPerView;
     } else {
-        firstView = blockIdx.x / p.grpPerView;
+        firstView = bid / p.grpPerView;
         groupViews = 1;
-        firstTile = (blockIdx.x - firstView * p.grpPerView) * p.grpChunkTiles;
+        firstTile = (bid - firstView * p.grpPerView) * p.grpChunkTiles;
         groupTiles = min(p.grpChunkTiles, tilesPerView - firstTile);
     }
     // XCD-aware split (see launchRaster; one-tile views, four per group):
@@ -1336,6 +1343,9 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         q.xcdSkew = (skewable && numGroups >= kFill) ? (vg == 4 ? 3u : 1u) : 0u;
         if (p.xcdSkewWanted >= 0)
             q.xcdSkew = skewable ? (uint32_t)(p.xcdSkewWanted < 8 ? p.xcdSkewWanted : 7) : 0u;
+        q.xcdRotate = (tpv == 1 && numGroups >= kFill) ? 1u : 0u;
+        if (p.xcdRotateWanted >= 0)
+            q.xcdRotate = p.xcdRotateWanted ? 1u : 0u;
         const dim3 grid(numGroups);
         const dim3 gblock(kWave * groupWaves(p.anyTextured != 0));
 #define MRX_GROUP(S)                                                           \

@@ -103,6 +103,10 @@ struct RasterParams {
     // MRX_XCD_SKEW override: -1 automatic, 0 off, 1..7 strips.
     uint32_t xcdSkew;
     int32_t xcdSkewWanted;
+    // rotate the group <-> XCD relation by two every round of eight workgroups
+    // (MRX_XCD_ROTATE override: -1 automatic, 0 off, 1 on)
+    uint32_t xcdRotate;
+    int32_t xcdRotateWanted;
     int32_t debugSlots;              // MRX_DEBUG_SLOTS: force 32 / 64 triangle slots per tile
     // Diagnostic only (MRX_DEBUG_STAMPS=1): per-wave s_memrealtime stamps,
     // [workgroup][wave][8], written to memory nothing else reads.

@@ -94,6 +94,7 @@ def test_random_scenes_under_random_kernel_shapes(native, monkeypatch, seed):
     if rng.integers(0, 2):
         env["MRX_GROUP_VIEWS"] = str([1, 2, 4][int(rng.integers(0, 3))])
         env["MRX_XCD_SKEW"] = str(int(rng.integers(0, 8)))
+        env["MRX_XCD_ROTATE"] = str(int(rng.integers(0, 2)))
     else:
         env["MRX_GROUP_TILES"] = str(int(rng.integers(1, 17)))
     if rng.integers(0, 4) == 0:

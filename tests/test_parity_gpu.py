@@ -56,6 +56,7 @@ def test_synthetic_scenes(native, kw):
 @pytest.mark.parametrize("views,strips", [(4, 0), (4, 1), (4, 3), (4, 7), (2, 0), (2, 1), (2, 5)])
 @pytest.mark.parametrize("kw", [
     dict(num_worlds=64),
+    dict(num_worlds=150),                                # 38 groups of 4: four full rounds and a partial one
     dict(num_worlds=7),                                  # odd workgroup count: unpaired last group
     dict(num_worlds=9, textured=True),                   # four-wave variant, second classify pass
     dict(num_worlds=13, render_mode="Raytracer"),        # transposed storage, segmask
@@ -67,6 +68,7 @@ def test_xcd_aware_split_forced_on_small_batches(native, monkeypatch, kw, views,
     # workgroups that carry an extra view
     monkeypatch.setenv("MRX_GROUP_VIEWS", str(views))
     monkeypatch.setenv("MRX_XCD_SKEW", str(strips))
+    monkeypatch.setenv("MRX_XCD_ROTATE", str(strips & 1))     # ... with and without the round rotation
     _parity(scenes.synthetic_scene(**kw))
 
 
