@@ -82,7 +82,7 @@ struct DevBuf {
     }
 };
 
-// The output tensors of a renderer live in ONE allocation, rgb first.  A lane
+// The output tensors of a renderer normally live in ONE allocation, rgb first.  A lane
 // stores the same pixels of every tensor back to back, and when two tensors
 // lie a multiple of 512 KiB apart those stores collide in the memory system
 // (measured: a 64 MiB + 64 MiB render takes 24.1 us at distance = 0 mod 512 KiB
@@ -97,13 +97,34 @@ size_t outPhase(const char *env, size_t dflt)
         return (size_t)std::atoll(dbg) << 10;
     return dflt;
 }
-hipError_t allocOutputs(size_t px, bool wantIds, DevBuf<uint32_t> &rgb, DevBuf<float> &depth,
-                        DevBuf<int32_t> &ids)
+hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint32_t> &rgb,
+                        DevBuf<float> &depth, DevBuf<int32_t> &ids)
 {
+    const size_t depthPhase = outPhase("MRX_OUT_SKEW_DEPTH_KB", 256u << 10);
+    const size_t idsPhase = outPhase("MRX_OUT_SKEW_IDS_KB", 64u << 10);
+    if (!oneAllocation) {
+        // One allocation per tensor, made back to back, the phases applied
+        // inside the (2 MiB-aligned) blocks.  Whether that yields the intended
+        // distance is up to the allocator -- this is the other kind of
+        // candidate of the placement search: half-GiB outputs were only ever
+        // fast this way, 128 MiB ones reliably only in one allocation.
+        hipError_t e = rgb.alloc(px);
+        if (e == hipSuccess) {
+            e = depth.alloc(px, depthPhase);
+            depth.ptr = reinterpret_cast<float *>(static_cast<char *>(depth.base) + depthPhase);
+        }
+        if (e == hipSuccess && wantIds) {
+            e = ids.alloc(px, idsPhase);
+            ids.ptr = reinterpret_cast<int32_t *>(static_cast<char *>(ids.base) + idsPhase);
+        }
+        if (e != hipSuccess) {
+            rgb.release(); depth.release(); ids.release();
+        }
+        return e;
+    }
     const size_t tb = (px * 4 + kOutPeriod - 1) / kOutPeriod * kOutPeriod;
-    const size_t depthOff = tb + outPhase("MRX_OUT_SKEW_DEPTH_KB", 256u << 10);
-    const size_t idsOff = depthOff + tb + kOutPeriod - (depthOff % kOutPeriod) +
-                          outPhase("MRX_OUT_SKEW_IDS_KB", 64u << 10);
+    const size_t depthOff = tb + depthPhase;
+    const size_t idsOff = depthOff + tb + kOutPeriod - (depthOff % kOutPeriod) + idsPhase;
     const size_t total = (wantIds ? idsOff : depthOff) + px * 4;
     const hipError_t e = rgb.alloc(px, total - px * 4);
     if (e != hipSuccess)
@@ -440,7 +461,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // image y (callers read it as [x][y]: scripts/test.py:160, dump.cpp:9-21)
     const uint32_t nfast = rt ? H : W, nslow = rt ? W : H;
     const size_t px = (size_t)nviews * nfast * nslow;
-    MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), r.rgb, r.depth, r.ids));
+    MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), true, r.rgb, r.depth, r.ids));
     const bool wantIds = rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS);
 
     RasterParams &p = r.params;
@@ -590,8 +611,9 @@ int mrx_device_count(void)
 // stores 7 % (128 MiB of output) to 20 % (0.5 - 3 GiB) faster into some
 // allocations than into others, steadily for the life of the allocation and
 // whatever the kernel does ("placement").  Nothing visible from
-// user space predicts which, so candidates are allocated one after another,
-// with spacers of varying size between them, each is timed with a few renders,
+// user space predicts which, so candidates are allocated one after another --
+// alternately all tensors in one allocation and one allocation per tensor,
+// with spacers of varying size between them --, each is timed with a few renders,
 // and the search stops as soon as one is clearly faster than the slowest seen
 // (or the timings show a single mode).  The fastest is kept, the rest freed.
 static int choosePlacement(mrx_renderer *r)
@@ -658,7 +680,7 @@ static int choosePlacement(mrx_renderer *r)
         else
             (void)hipGetLastError();
         Cand c;
-        if (allocOutputs(px, wantIds, c.rgb, c.depth, c.ids) != hipSuccess) {
+        if (allocOutputs(px, wantIds, (k & 1) == 0, c.rgb, c.depth, c.ids) != hipSuccess) {
             (void)hipGetLastError();                  // out of memory: make do with what there is
             break;
         }
@@ -672,7 +694,7 @@ static int choosePlacement(mrx_renderer *r)
         tmax = std::max(tmax, us);
         if (tmin <= 0.965f * tmax)
             break;                                    // a fast placement
-        if (k >= (bytes <= (256ull << 20) ? 2 : 7) && tmin >= 0.985f * tmax)
+        if (bytes <= (256ull << 20) ? k >= 3 : (k >= 7 && tmin >= 0.985f * tmax))
             break;                                    // a single mode: nothing to find
     }
     if (trace) {
