@@ -127,7 +127,7 @@ def main():
     kern_us = dev_ms * 1000.0 / a.steps
     achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
     out = {
-        "metric": "rendered views/sec (whole node), N worlds x 64x64 RGB+depth",
+        "metric": "rendered views/sec (whole node), N worlds x %dx%d RGB+depth" % (a.width, a.height),
         "value": value,
         "unit": "views/s",
         "n_gpus": n_gpus,
