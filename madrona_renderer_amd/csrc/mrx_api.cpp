@@ -615,14 +615,13 @@ int mrx_device_count(void)
 // alternately all tensors in one allocation and one allocation per tensor,
 // with spacers of varying size between them --, each is timed with a few renders,
 // and the search stops as soon as one is clearly faster than the slowest seen
-// (or the timings show a single mode).  The fastest is kept, the rest freed.
+// (small outputs: after four).  The fastest is kept, the rest freed.
 static int choosePlacement(mrx_renderer *r)
 {
     const size_t px = r->rgb.count;
     const bool wantIds = r->ids.ptr != nullptr;
     const size_t bytes = px * 4 * (wantIds ? 3 : 2);
-    int maxTries = bytes == 0 ? 1 : bytes <= (256ull << 20) ? 16 : bytes <= (2ull << 30) ? 12
-                 : bytes <= (8ull << 30) ? 8 : 1;
+    int maxTries = bytes == 0 ? 1 : bytes <= (256ull << 20) ? 16 : bytes <= (8ull << 30) ? 12 : 1;
     if (const char *dbg = std::getenv("MRX_PLACEMENT_TRIES"))
         maxTries = std::max(1, std::min(32, std::atoi(dbg)));
     if (maxTries <= 1)
@@ -694,8 +693,8 @@ static int choosePlacement(mrx_renderer *r)
         tmax = std::max(tmax, us);
         if (tmin <= 0.965f * tmax)
             break;                                    // a fast placement
-        if (bytes <= (256ull << 20) ? k >= 3 : (k >= 7 && tmin >= 0.985f * tmax))
-            break;                                    // a single mode: nothing to find
+        if (bytes <= (256ull << 20) && k >= 3)
+            break;                                    // small outputs: one block is reliably fast
     }
     if (trace) {
         std::fprintf(stderr, "mrx: output placement, us/render:");

@@ -1310,14 +1310,21 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         constexpr uint32_t kFill = 1024;          // 256 CUs x 4 resident workgroups
         RasterParams q = p;
         uint32_t vg = 1, ct = tpv, gpv = 1;
-        if (tpv <= maxTiles) {
-            vg = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)(kChunk / slots), maxTiles / tpv));
+        if (tpv == 1) {
+            // one-tile views: as many as fit 64 records; all workgroups resident
+            vg = std::max<uint32_t>(1u, (uint32_t)(kChunk / slots));
             while (vg > 1 && (p.numViews + vg - 1) / vg < kFill)
                 vg /= 2;
+        } else if (p.anyTextured) {
+            // textured, several tiles per view: a quarter of a view per workgroup, at most four
+            // tiles (4 waves per workgroup and per-pixel texturing make a tile long enough for
+            // its own setup; measured on 128^2 and 256^2: profiles/r01_group_shapes.txt)
+            ct = std::max<uint32_t>(1u, std::min<uint32_t>(4u, tpv / 4u));
         } else {
-            ct = maxTiles;
+            // untextured, several tiles per view: one view per workgroup, at most eight tiles
+            ct = std::min<uint32_t>(tpv, std::min<uint32_t>(maxTiles, 8u));
         }
-        if (vg == 1)
+        if (tpv != 1)
             while (ct > 1 && (uint64_t)p.numViews * ((tpv + ct - 1) / ct) < kFill)
                 ct = (ct + 1) / 2;
         if (p.grpViewsWanted > 0 && tpv * (uint32_t)p.grpViewsWanted <= maxTiles &&
