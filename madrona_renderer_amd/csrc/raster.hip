@@ -1311,8 +1311,11 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         RasterParams q = p;
         uint32_t vg = 1, ct = tpv, gpv = 1;
         if (tpv == 1) {
-            // one-tile views: as many as fit 64 records; all workgroups resident
+            // one-tile views: as many as fit 64 records, all workgroups resident
+            // (textured: two -- its workgroups have four waves and longer tiles)
             vg = std::max<uint32_t>(1u, (uint32_t)(kChunk / slots));
+            if (p.anyTextured)
+                vg = std::min<uint32_t>(vg, 2u);
             while (vg > 1 && (p.numViews + vg - 1) / vg < kFill)
                 vg /= 2;
         } else if (p.anyTextured) {

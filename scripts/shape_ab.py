@@ -11,6 +11,8 @@ K = {
     "T128": dict(num_worlds=4096, width=128, height=128, textured=True),
     "U512": dict(num_worlds=1024, width=512, height=512),
     "T256s": dict(num_worlds=1024, width=256, height=256, textured=True),
+    "T64": dict(num_worlds=4096, textured=True),
+    "TW64": dict(num_worlds=4096, textured=True, with_wall=True),
     "U128s": dict(num_worlds=1024, width=128, height=128),
 }
 name = sys.argv[1]
