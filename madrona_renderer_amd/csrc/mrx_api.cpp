@@ -97,6 +97,10 @@ size_t outPhase(const char *env, size_t dflt)
         return (size_t)std::atoll(dbg) << 10;
     return dflt;
 }
+// Which kind of candidate the placement search starts with: tensors of 64 MiB
+// were reliably fast in one block, tensors of 256 MiB and 1 GiB one block each.
+bool firstKindIsOneBlock(size_t px) { return px * 4 < (128ull << 20); }
+
 hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint32_t> &rgb,
                         DevBuf<float> &depth, DevBuf<int32_t> &ids)
 {
@@ -461,7 +465,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // image y (callers read it as [x][y]: scripts/test.py:160, dump.cpp:9-21)
     const uint32_t nfast = rt ? H : W, nslow = rt ? W : H;
     const size_t px = (size_t)nviews * nfast * nslow;
-    MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), true, r.rgb, r.depth, r.ids));
+    MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), firstKindIsOneBlock(px), r.rgb, r.depth, r.ids));
     const bool wantIds = rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS);
 
     RasterParams &p = r.params;
@@ -679,7 +683,7 @@ static int choosePlacement(mrx_renderer *r)
         else
             (void)hipGetLastError();
         Cand c;
-        if (allocOutputs(px, wantIds, (k & 1) == 0, c.rgb, c.depth, c.ids) != hipSuccess) {
+        if (allocOutputs(px, wantIds, ((k & 1) == 0) == firstKindIsOneBlock(px), c.rgb, c.depth, c.ids) != hipSuccess) {
             (void)hipGetLastError();                  // out of memory: make do with what there is
             break;
         }
