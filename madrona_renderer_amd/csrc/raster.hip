@@ -1316,7 +1316,9 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
             vg = std::max<uint32_t>(1u, (uint32_t)(kChunk / slots));
             if (p.anyTextured)
                 vg = std::min<uint32_t>(vg, 2u);
-            while (vg > 1 && (p.numViews + vg - 1) / vg < kFill)
+            // ... until ~4 workgroups per CU remain; two views per workgroup are kept
+            // down to 2 per CU (1024 worlds: 9.9 -> 9.3 us)
+            while (vg > 1 && (p.numViews + vg - 1) / vg < (vg == 2 ? kFill / 2 : kFill))
                 vg /= 2;
         } else if (p.anyTextured) {
             // textured, several tiles per view: a quarter of a view per workgroup, at most four

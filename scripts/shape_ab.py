@@ -11,6 +11,9 @@ K = {
     "T128": dict(num_worlds=4096, width=128, height=128, textured=True),
     "U512": dict(num_worlds=1024, width=512, height=512),
     "T256s": dict(num_worlds=1024, width=256, height=256, textured=True),
+    "C2": dict(num_worlds=1024),
+    "C4": dict(num_worlds=2048),
+    "W512": dict(num_worlds=512),
     "T64": dict(num_worlds=4096, textured=True),
     "TW64": dict(num_worlds=4096, textured=True, with_wall=True),
     "U128s": dict(num_worlds=1024, width=128, height=128),
