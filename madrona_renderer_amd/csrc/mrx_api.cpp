@@ -102,7 +102,8 @@ size_t outPhase(const char *env, size_t dflt)
 bool firstKindIsOneBlock(size_t px) { return px * 4 < (128ull << 20); }
 
 hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint32_t> &rgb,
-                        DevBuf<float> &depth, DevBuf<int32_t> &ids)
+                        DevBuf<float> &depth, DevBuf<int32_t> &ids,
+                        std::vector<DevBuf<uint8_t>> *spacers = nullptr, size_t gapBytes = 0)
 {
     const size_t depthPhase = outPhase("MRX_OUT_SKEW_DEPTH_KB", 256u << 10);
     const size_t idsPhase = outPhase("MRX_OUT_SKEW_IDS_KB", 64u << 10);
@@ -113,11 +114,18 @@ hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint
         // candidate of the placement search: half-GiB outputs were only ever
         // fast this way, 128 MiB ones reliably only in one allocation.
         hipError_t e = rgb.alloc(px);
+        auto gap = [&]() {                            // the search also varies what lies between the tensors
+            DevBuf<uint8_t> sp;
+            if (spacers && gapBytes && sp.alloc(gapBytes) == hipSuccess)
+                spacers->push_back(sp);
+        };
         if (e == hipSuccess) {
+            gap();
             e = depth.alloc(px, depthPhase);
             depth.ptr = reinterpret_cast<float *>(static_cast<char *>(depth.base) + depthPhase);
         }
         if (e == hipSuccess && wantIds) {
+            gap();
             e = ids.alloc(px, idsPhase);
             ids.ptr = reinterpret_cast<int32_t *>(static_cast<char *>(ids.base) + idsPhase);
         }
@@ -683,7 +691,9 @@ static int choosePlacement(mrx_renderer *r)
         else
             (void)hipGetLastError();
         Cand c;
-        if (allocOutputs(px, wantIds, ((k & 1) == 0) == firstKindIsOneBlock(px), c.rgb, c.depth, c.ids) != hipSuccess) {
+        static const size_t kGapsMiB[6] = { 0, 2, 34, 66, 18, 98 };
+        if (allocOutputs(px, wantIds, ((k & 1) == 0) == firstKindIsOneBlock(px), c.rgb, c.depth, c.ids,
+                         &spacers, kGapsMiB[(k / 2) % 6] << 20) != hipSuccess) {
             (void)hipGetLastError();                  // out of memory: make do with what there is
             break;
         }
