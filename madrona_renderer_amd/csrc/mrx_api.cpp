@@ -686,7 +686,10 @@ static int choosePlacement(mrx_renderer *r)
     for (int k = 1; k < maxTries; ++k) {
         // spacers of 2 ... 128 MiB step the candidates through the address space
         DevBuf<uint8_t> sp;
-        if (sp.alloc((size_t)(2 * ((k * 37) % 64 + 1)) << 20) == hipSuccess)
+        // (large outputs: also by multiples of half their size, out of the holes
+        // earlier renderers of the process left behind)
+        const size_t hop = bytes > (256ull << 20) ? (size_t)(k % 4) * (bytes / 2) : 0;
+        if (sp.alloc(hop + ((size_t)(2 * ((k * 37) % 64 + 1)) << 20)) == hipSuccess)
             spacers.push_back(sp);
         else
             (void)hipGetLastError();
@@ -706,8 +709,8 @@ static int choosePlacement(mrx_renderer *r)
         }
         tmax = std::max(tmax, us);
         // the two modes lie 7 % (small outputs) to 20 % apart; candidates of one
-        // mode scatter by +-0.5 % (small) to +-2 % (large)
-        if (tmin <= (bytes <= (256ull << 20) ? 0.965f : 0.92f) * tmax)
+        // mode scatter by +-0.5 % (small) to +-4 % (large)
+        if (tmin <= (bytes <= (256ull << 20) ? 0.965f : 0.88f) * tmax)
             break;                                    // a fast placement
         if (bytes <= (256ull << 20) && k >= 3)
             break;                                    // small outputs: one block is reliably fast
