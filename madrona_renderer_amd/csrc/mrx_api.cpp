@@ -661,14 +661,15 @@ static int choosePlacement(mrx_renderer *r)
         return e;
     };
     // a render takes ~10 us to ~1 ms: batches of ~0.5 ms, ~40 ms of warm-up (clocks)
+    hipError_t st = hipSuccess;                   // first error; the cleanup below always runs
     bind(cand[0]);
     float one = 0.0f;
-    MRX_HIP(launch());
-    MRX_HIP(timeBatch(1, one));
+    st = launch();
+    if (st == hipSuccess) st = timeBatch(1, one);
     one = std::max(one, 1e-3f);
     const int batch = std::max(3, std::min(64, (int)(0.5f / one)));
     float scratch = 0.0f;
-    MRX_HIP(timeBatch(std::max(8, std::min(4000, (int)(40.0f / one))), scratch));
+    if (st == hipSuccess) st = timeBatch(std::max(8, std::min(4000, (int)(40.0f / one))), scratch);
     auto measure = [&](Cand &c) -> hipError_t {
         bind(c);
         hipError_t e = launch();
@@ -680,10 +681,10 @@ static int choosePlacement(mrx_renderer *r)
         c.us = best / (float)batch * 1000.0f;
         return e;
     };
-    MRX_HIP(measure(cand[0]));
+    if (st == hipSuccess) st = measure(cand[0]);
     float tmin = cand[0].us, tmax = cand[0].us;
     int best = 0;
-    for (int k = 1; k < maxTries; ++k) {
+    for (int k = 1; k < maxTries && st == hipSuccess; ++k) {
         // spacers of 2 ... 128 MiB step the candidates through the address space
         DevBuf<uint8_t> sp;
         // (large outputs: also by multiples of half their size, out of the holes
@@ -701,7 +702,9 @@ static int choosePlacement(mrx_renderer *r)
             break;
         }
         cand.push_back(c);
-        MRX_HIP(measure(cand.back()));
+        st = measure(cand.back());
+        if (st != hipSuccess)
+            break;
         const float us = cand.back().us;
         if (us < tmin) {
             tmin = us;
@@ -734,6 +737,8 @@ static int choosePlacement(mrx_renderer *r)
     }
     r->rgb = cand[best].rgb; r->depth = cand[best].depth; r->ids = cand[best].ids;
     bind(cand[best]);
+    if (st != hipSuccess)
+        return fail(MRX_E_HIP, std::string("output placement: ") + hipGetErrorString(st));
     return MRX_OK;
 }
 
