@@ -94,6 +94,7 @@ public:
     float elapsedMs();                              // event1 - event0, waits for 1
     uint64_t bytesPerStep() const;                  // algorithmic HBM bytes / render
     void *nativeHandle() const;                     // mrx_renderer *
+    void setStream(void *hipStream);                // launch on this stream from now on
 
     uint32_t numAgents;
 

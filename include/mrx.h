@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MRX_ABI_VERSION 1
+#define MRX_ABI_VERSION 2
 
 enum {
     MRX_OK = 0,
@@ -173,6 +173,13 @@ int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes);
 
 int mrx_info(mrx_renderer *r, mrx_info_t *out);
 void *mrx_stream(mrx_renderer *r);
+/* -- stream: later launches are enqueued on `stream` (a hipStream_t; NULL = the
+ *    device's null stream).  Work already enqueued on the old stream is waited
+ *    for first, so the switch never reorders two renders.  A caller that
+ *    writes the pose tensors from its own stream (e.g. a non-default torch
+ *    stream) passes that stream here and needs no host synchronisation between
+ *    the write and mrx_step(): both are ordered on the one stream. */
+int mrx_set_stream(mrx_renderer *r, void *stream);
 
 /* -- measurement: enqueue `steps` back-to-back mrx_render launches between
  *    two HIP events on the renderer's stream; *ms_total = elapsed device ms.

@@ -185,4 +185,10 @@ uint64_t Manager::bytesPerStep() const
 
 void *Manager::nativeHandle() const { return impl_->r; }
 
+void Manager::setStream(void *hipStream)
+{
+    if (mrx_set_stream(impl_->r, hipStream) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
 }  // namespace madRender

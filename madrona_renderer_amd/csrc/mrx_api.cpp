@@ -192,19 +192,18 @@ struct mrx_renderer {
 
 namespace {
 
-// S6b support: is the object a closed, consistently wound triangle mesh?
-// Vertices are welded by exact position; closed <=> every directed edge occurs
-// once and so does its reverse.  Returns the sign of the enclosed volume
-// (+1 outward winding, -1 inward) or 0 when the mesh is open / inconsistent.
-float closedOrientation(const mrx::ObjTri *tris, uint32_t n)
+// S6b support.  An object may hold several shells (edge-connected components);
+// each is judged on its own: closed and consistently wound <=> every directed
+// edge of the component occurs once and so does its reverse (vertices welded
+// by exact position).  Per triangle: orient = the sign of its component's
+// enclosed volume (+1 outward winding, -1 inward; 0 when the component is
+// open / inconsistent, which leaves its triangles two-sided) and the
+// component's bounding box, padded by 1e-4 of its extent + 1e-6.
+void shellOrientation(const mrx::ObjTri *tris, uint32_t n, mrx::TriMat *mats)
 {
-    if (n < 4)
-        return 0.0f;
     std::map<std::array<uint32_t, 3>, uint32_t> ids;
-    std::map<std::pair<uint32_t, uint32_t>, int> edges;
-    double vol = 0.0;
-    for (uint32_t t = 0; t < n; ++t) {
-        uint32_t v[3];
+    std::vector<std::array<uint32_t, 3>> tv(n);
+    for (uint32_t t = 0; t < n; ++t)
         for (int c = 0; c < 3; ++c) {
             std::array<uint32_t, 3> key;
             std::memcpy(key.data(), tris[t].p + 3 * c, 12);
@@ -213,24 +212,73 @@ float closedOrientation(const mrx::ObjTri *tris, uint32_t n)
             auto it = ids.find(key);
             if (it == ids.end())
                 it = ids.emplace(key, (uint32_t)ids.size()).first;
-            v[c] = it->second;
+            tv[t][c] = it->second;
         }
+    // components: triangles joined through a shared (undirected) edge
+    std::vector<uint32_t> parent(n);
+    for (uint32_t t = 0; t < n; ++t)
+        parent[t] = t;
+    auto find = [&](uint32_t x) {
+        while (parent[x] != x)
+            x = parent[x] = parent[parent[x]];
+        return x;
+    };
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> firstOnEdge;
+    for (uint32_t t = 0; t < n; ++t)
+        for (int c = 0; c < 3; ++c) {
+            uint32_t a = tv[t][c], b = tv[t][(c + 1) % 3];
+            if (a > b) std::swap(a, b);
+            auto ins = firstOnEdge.emplace(std::make_pair(a, b), t);
+            if (!ins.second)
+                parent[find(t)] = find(ins.first->second);
+        }
+    struct Shell {
+        std::map<std::pair<uint32_t, uint32_t>, int> edges;
+        double vol = 0.0;
+        bool bad = false;
+        uint32_t count = 0;
+        float lo[3], hi[3];
+    };
+    std::map<uint32_t, Shell> shells;
+    for (uint32_t t = 0; t < n; ++t) {
+        Shell &sh = shells[find(t)];
+        const uint32_t *v = tv[t].data();
         if (v[0] == v[1] || v[1] == v[2] || v[2] == v[0])
-            return 0.0f;
+            sh.bad = true;
         for (int c = 0; c < 3; ++c)
-            if (++edges[{ v[c], v[(c + 1) % 3] }] > 1)
-                return 0.0f;
+            if (++sh.edges[{ v[c], v[(c + 1) % 3] }] > 1)
+                sh.bad = true;
         const float *a = tris[t].p, *b = a + 3, *c3 = a + 6;
-        vol += (double)a[0] * ((double)b[1] * c3[2] - (double)b[2] * c3[1]) +
-               (double)a[1] * ((double)b[2] * c3[0] - (double)b[0] * c3[2]) +
-               (double)a[2] * ((double)b[0] * c3[1] - (double)b[1] * c3[0]);
+        sh.vol += (double)a[0] * ((double)b[1] * c3[2] - (double)b[2] * c3[1]) +
+                  (double)a[1] * ((double)b[2] * c3[0] - (double)b[0] * c3[2]) +
+                  (double)a[2] * ((double)b[0] * c3[1] - (double)b[1] * c3[0]);
+        for (int c = 0; c < 3; ++c)
+            for (int ax = 0; ax < 3; ++ax) {
+                const float x = tris[t].p[3 * c + ax];
+                if ((sh.count == 0 && c == 0) || x < sh.lo[ax]) sh.lo[ax] = x;
+                if ((sh.count == 0 && c == 0) || x > sh.hi[ax]) sh.hi[ax] = x;
+            }
+        sh.count++;
     }
-    for (const auto &e : edges) {
-        auto rev = edges.find({ e.first.second, e.first.first });
-        if (rev == edges.end())
-            return 0.0f;
+    for (auto &kv : shells) {
+        Shell &sh = kv.second;
+        if (sh.count < 4)
+            sh.bad = true;
+        for (const auto &e : sh.edges)
+            if (!sh.bad && sh.edges.find({ e.first.second, e.first.first }) == sh.edges.end())
+                sh.bad = true;
+        for (int ax = 0; ax < 3; ++ax) {
+            const float pad = 1e-4f * (sh.hi[ax] - sh.lo[ax]) + 1e-6f;
+            sh.lo[ax] -= pad;
+            sh.hi[ax] += pad;
+        }
     }
-    return vol > 0.0 ? 1.0f : vol < 0.0 ? -1.0f : 0.0f;
+    for (uint32_t t = 0; t < n; ++t) {
+        const Shell &sh = shells[find(t)];
+        mats[t].orient = sh.bad ? 0.0f : sh.vol > 0.0 ? 1.0f : sh.vol < 0.0 ? -1.0f : 0.0f;
+        std::memcpy(mats[t].bbMin, sh.lo, 12);
+        std::memcpy(mats[t].bbMax, sh.hi, 12);
+    }
 }
 
 int buildScene(const mrx_config &cfg, mrx_renderer &r)
@@ -378,29 +426,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         if (tm.tex < 0 || (uint32_t)tm.tex >= (uint32_t)texDescs.size())
             tm.tex = -1;
     }
-    // S6b: per-object orientation and padded bounding box, copied per triangle
-    for (size_t o = 0; o < r.objFirst.size(); ++o) {
-        const uint32_t f = (uint32_t)r.objFirst[o], n = (uint32_t)r.objCount[o];
-        const float orient = closedOrientation(tris.data() + f, n);
-        float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
-        for (uint32_t t = 0; t < n; ++t)
-            for (int c = 0; c < 3; ++c)
-                for (int a = 0; a < 3; ++a) {
-                    const float x = tris[f + t].p[3 * c + a];
-                    if ((t == 0 && c == 0) || x < lo[a]) lo[a] = x;
-                    if ((t == 0 && c == 0) || x > hi[a]) hi[a] = x;
-                }
-        for (int a = 0; a < 3; ++a) {
-            const float pad = 1e-4f * (hi[a] - lo[a]) + 1e-6f;
-            lo[a] -= pad;
-            hi[a] += pad;
-        }
-        for (uint32_t t = 0; t < n; ++t) {
-            triMats[f + t].orient = orient;
-            std::memcpy(triMats[f + t].bbMin, lo, 12);
-            std::memcpy(triMats[f + t].bbMax, hi, 12);
-        }
-    }
+    // S6b: orientation and padded bounding box of every triangle's shell
+    for (size_t o = 0; o < r.objFirst.size(); ++o)
+        shellOrientation(tris.data() + r.objFirst[o], (uint32_t)r.objCount[o],
+                         triMats.data() + r.objFirst[o]);
 
     // ---- world assembly: per-world copies of the table rows, world-major
     //      (/root/reference/src/sim.cpp:143-175)
@@ -544,6 +573,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.oz = (float)((1.0 - 1.0 / (double)H) * (double)th);
     p.invNear = 1.0f / (rt ? kRtZNear : kRasterZNear);
     p.invFar = rt ? 1.0f / kRtZFar : 0.0f;
+    // S6b pad: a surface point nearer than znear along +Y that still projects
+    // into the image lies within znear * |longest ray| of the eye
+    p.s6bPad = (float)((double)(rt ? kRtZNear : kRasterZNear) *
+                       std::sqrt(1.0 + (double)th * (double)th * (1.0 + asp * asp)) * 1.001);
     const double ln = std::sqrt(kLightDir[0] * kLightDir[0] + kLightDir[1] * kLightDir[1] +
                                 kLightDir[2] * kLightDir[2]);
     for (int c = 0; c < 3; ++c)
@@ -842,6 +875,20 @@ int mrx_sync(mrx_renderer *r)
 }
 
 void *mrx_stream(mrx_renderer *r) { return r ? (void *)r->stream : nullptr; }
+
+int mrx_set_stream(mrx_renderer *r, void *stream)
+{
+    if (!r)
+        return fail(MRX_E_INVALID, "null renderer");
+    MRX_HIP(hipSetDevice(r->device));
+    if ((hipStream_t)stream == r->stream)
+        return MRX_OK;
+    // renders already enqueued on the old stream finish before anything that
+    // is enqueued on the new one can start
+    MRX_HIP(hipStreamSynchronize(r->stream));
+    r->stream = (hipStream_t)stream;
+    return MRX_OK;
+}
 
 void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dtype,
                  int *device)

@@ -228,6 +228,15 @@ PYBIND11_MODULE(madrona_renderer, m)
                      throw py::value_error("mesh_uvs must have shape [N, 2]");
                  if ((size_t)num_worlds != worlds.size())
                      throw py::value_error("num_worlds does not match len(worlds)");
+                 // the C ABI carries no lengths for the per-mesh arrays and reads
+                 // uvs row-for-row with vertices: check them here
+                 if (mesh_indices_offsets.size() != mesh_vertex_offsets.size() ||
+                     mesh_materials.size() != mesh_vertex_offsets.size())
+                     throw py::value_error("mesh_vertex_offsets, mesh_indices_offsets and "
+                                           "mesh_materials must have one entry per mesh");
+                 if ((mesh_uvs.size() ? mesh_uvs.shape(0) : 0) !=
+                     (mesh_vertices.size() ? mesh_vertices.shape(0) : 0))
+                     throw py::value_error("mesh_uvs must have one row per row of mesh_vertices");
                  std::vector<const char *> cstrs(asset_paths.size());
                  std::vector<int32_t> mat_assignments(asset_paths.size());
                  for (size_t i = 0; i < asset_paths.size(); ++i) {
@@ -311,5 +320,9 @@ PYBIND11_MODULE(madrona_renderer, m)
         .def("elapsed_ms", &Manager::elapsedMs)
         .def("bytes_per_step", &Manager::bytesPerStep)
         .def("native_handle", [](Manager &self) { return (uint64_t)self.nativeHandle(); })
+        // e.g. r.set_stream(torch.cuda.current_stream().cuda_stream): pose writes and
+        // step() are then ordered on that stream without a host synchronisation
+        .def("set_stream", [](Manager &self, uint64_t stream) { self.setStream((void *)stream); },
+             py::arg("stream"))
         .def_readonly("num_agents", &Manager::numAgents);
 }

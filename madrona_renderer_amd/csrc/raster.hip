@@ -129,9 +129,9 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
     const float4 *msrc = reinterpret_cast<const float4 *>(p.triMats + wt.tri);
     const float4 mc = msrc[0], m1 = msrc[1], m2 = msrc[2];
     const int32_t tex = __float_as_int(m1.x);
-    // S6b: is the eye outside the object's (padded) bounding box?  The eye in
-    // the instance's unscaled frame, q = Ri^T (c - t), against the box scaled
-    // by s (no division).
+    // S6b: is the eye outside the (padded) bounding box of the triangle's shell,
+    // by more than the reach of the near plane?  The eye in the instance's
+    // unscaled frame, q = Ri^T (c - t), against the box scaled by s (no division).
     bool cullBack = false, cullFront = false;
     {
         const float orient = m1.y;
@@ -141,7 +141,7 @@ __device__ __forceinline__ bool setupTriangle(const RasterParams &p,
         for (int r = 0; r < 3; ++r) {
             const float qo = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]);
             const float b0 = bmin[r] * sc[r], b1 = bmax[r] * sc[r];
-            outside = outside || qo < fminf(b0, b1) || qo > fmaxf(b0, b1);
+            outside = outside || qo < fminf(b0, b1) - p.s6bPad || qo > fmaxf(b0, b1) + p.s6bPad;
         }
         const float handed = orient * ((s0 * s1) * s2);   // mirroring flips the winding
         cullBack = outside && handed > 0.0f;

@@ -20,9 +20,10 @@ static_assert(sizeof(ObjTri) == 64, "ObjTri must be one 64-byte line");
 struct alignas(16) TriMat {
     float color[4];
     int32_t tex;       // texture index, -1 = untextured
-    // S6b back-face culling data of the triangle's object: orient = +1 / -1
-    // when the object is a closed, consistently wound mesh (sign of its
-    // volume), 0 otherwise; bb = its object-space bounding box, padded
+    // S6b back-face culling data of the triangle's shell (edge-connected
+    // component of its object): orient = +1 / -1 when the shell is a closed,
+    // consistently wound mesh (sign of its volume), 0 otherwise; bb = the
+    // shell's object-space bounding box, padded
     float orient;
     float bbMin[3];
     float bbMax[3];
@@ -81,6 +82,9 @@ struct RasterParams {
     // pixel -> ray constants
     float sx, ox, sz, oz;
     float invNear, invFar;
+    // S6b: the eye counts as outside a shell only when it is further than this
+    // from the shell's box -- no front face can then be cut by the near plane
+    float s6bPad;
     float toLight[3];
     float ambient, diffuse;
     int32_t transposed;              // Raytracer-mode [x][y] storage

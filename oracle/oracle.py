@@ -46,8 +46,8 @@ class _Scene(ctypes.Structure):
         ("tri_pos", ctypes.c_void_p), ("tri_uv", ctypes.c_void_p),
         ("tri_mat", ctypes.c_void_p), ("obj_first_tri", ctypes.c_void_p),
         ("obj_num_tris", ctypes.c_void_p), ("num_objects", ctypes.c_int32),
-        ("obj_orient", ctypes.c_void_p), ("obj_bbmin", ctypes.c_void_p),
-        ("obj_bbmax", ctypes.c_void_p),
+        ("tri_orient", ctypes.c_void_p), ("tri_bbmin", ctypes.c_void_p),
+        ("tri_bbmax", ctypes.c_void_p),
         ("mat_color", ctypes.c_void_p), ("mat_tex", ctypes.c_void_p),
         ("num_materials", ctypes.c_int32),
         ("tex_data", ctypes.c_void_p), ("tex_offset", ctypes.c_void_p),
@@ -62,6 +62,7 @@ class _Scene(ctypes.Structure):
         ("sx", ctypes.c_float), ("ox", ctypes.c_float),
         ("sz", ctypes.c_float), ("oz", ctypes.c_float),
         ("inv_near", ctypes.c_float), ("inv_far", ctypes.c_float),
+        ("s6b_pad", ctypes.c_float),
         ("to_light", ctypes.c_float * 3),
         ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
         ("default_color", ctypes.c_float * 4),
@@ -171,44 +172,64 @@ def parse_mtl(path):
     return [tuple(m) for m in out]
 
 
-def closed_orientation(tri_pos):
-    """S6b: +1 / -1 (sign of the enclosed volume) when the triangle soup is a
-    closed, consistently wound mesh -- every directed edge occurs exactly once
-    and so does its reverse, vertices welded by exact position -- else 0."""
+def shell_orientation(tri_pos):
+    """S6b, per triangle of one object: (orient [T] f32, bbmin [T,3], bbmax [T,3]).
+
+    Triangles joined through a shared (undirected) edge form a shell, vertices
+    welded by exact position.  A shell is closed and consistently wound when
+    every directed edge occurs exactly once and so does its reverse; its
+    triangles then carry orient = the sign of the enclosed volume, else 0.
+    The box is the shell's, padded by 1e-4 of its extent + 1e-6 (float32)."""
     n = len(tri_pos)
-    if n < 4:
-        return 0.0
-    ids, edges = {}, {}
-    vol = 0.0
+    orient = np.zeros(n, np.float32)
+    bmin = np.zeros((n, 3), np.float32)
+    bmax = np.zeros((n, 3), np.float32)
+    if n == 0:
+        return orient, bmin, bmax
+    ids, tv = {}, []
     for t in range(n):
-        v = []
-        for c in range(3):
-            key = tuple(float(x) + 0.0 for x in tri_pos[t, c])     # -0 -> +0
-            v.append(ids.setdefault(key, len(ids)))
-        if len(set(v)) < 3:
-            return 0.0
-        for c in range(3):
-            e = (v[c], v[(c + 1) % 3])
-            if e in edges:
-                return 0.0
-            edges[e] = 1
-        a, b, c3 = (tri_pos[t, i].astype(np.float64) for i in range(3))
-        vol += float(a @ np.cross(b, c3))
-    for (i, j) in edges:
-        if (j, i) not in edges:
-            return 0.0
-    return 1.0 if vol > 0 else -1.0 if vol < 0 else 0.0
+        tv.append([ids.setdefault(tuple(float(x) + 0.0 for x in tri_pos[t, c]), len(ids))
+                   for c in range(3)])                              # -0 -> +0
+    parent = list(range(n))
 
-
-def padded_bounds(tri_pos):
-    """Object-space bounding box padded by 1e-4 of its extent + 1e-6 (float32)."""
-    if len(tri_pos) == 0:
-        z = np.zeros(3, np.float32)
-        return z, z
-    pts = tri_pos.reshape(-1, 3).astype(np.float32)
-    lo, hi = pts.min(axis=0), pts.max(axis=0)
-    pad = np.float32(1e-4) * (hi - lo) + np.float32(1e-6)
-    return (lo - pad).astype(np.float32), (hi + pad).astype(np.float32)
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    first = {}
+    for t in range(n):
+        for c in range(3):
+            e = tuple(sorted((tv[t][c], tv[t][(c + 1) % 3])))
+            if e in first:
+                parent[find(t)] = find(first[e])
+            else:
+                first[e] = t
+    shells = {}
+    for t in range(n):
+        shells.setdefault(find(t), []).append(t)
+    for members in shells.values():
+        edges, bad, vol = set(), len(members) < 4, 0.0
+        for t in members:
+            v = tv[t]
+            if len(set(v)) < 3:
+                bad = True
+            for c in range(3):
+                e = (v[c], v[(c + 1) % 3])
+                if e in edges:
+                    bad = True
+                edges.add(e)
+            a, b, c3 = (tri_pos[t, i].astype(np.float64) for i in range(3))
+            vol += float(a @ np.cross(b, c3))
+        if not bad and any((j, i) not in edges for (i, j) in edges):
+            bad = True
+        pts = tri_pos[members].reshape(-1, 3).astype(np.float32)
+        lo, hi = pts.min(axis=0), pts.max(axis=0)
+        pad = np.float32(1e-4) * (hi - lo) + np.float32(1e-6)
+        orient[members] = 0.0 if bad else (1.0 if vol > 0 else -1.0 if vol < 0 else 0.0)
+        bmin[members] = lo - pad
+        bmax[members] = hi + pad
+    return orient, bmin, bmax
 
 
 def decode_image(path):
@@ -316,15 +337,15 @@ class FlatScene:
             np.concatenate(mat_l) if mat_l else np.zeros(0), np.int32)
         self.obj_first_tri = np.asarray(first, dtype=np.int32)
         self.obj_num_tris = np.asarray(count, dtype=np.int32)
-        orient, bmin, bmax = [], [], []
+        T = len(self.tri_pos)
+        self.tri_orient = np.zeros(T, np.float32)
+        self.tri_bbmin = np.zeros((T, 3), np.float32)
+        self.tri_bbmax = np.zeros((T, 3), np.float32)
         for f, c in zip(first, count):
-            orient.append(closed_orientation(self.tri_pos[f:f + c]))
-            lo, hi = padded_bounds(self.tri_pos[f:f + c])
-            bmin.append(lo)
-            bmax.append(hi)
-        self.obj_orient = np.asarray(orient, dtype=np.float32)
-        self.obj_bbmin = np.asarray(bmin, dtype=np.float32).reshape(-1, 3)
-        self.obj_bbmax = np.asarray(bmax, dtype=np.float32).reshape(-1, 3)
+            o, lo, hi = shell_orientation(self.tri_pos[f:f + c])
+            self.tri_orient[f:f + c] = o
+            self.tri_bbmin[f:f + c] = lo
+            self.tri_bbmax[f:f + c] = hi
 
         # -- materials / textures (API ones first, then the files' own)
         texels, offs, tw, th = [], [], [], []
@@ -401,8 +422,8 @@ class FlatScene:
         s.obj_first_tri = ptr(self.obj_first_tri)
         s.obj_num_tris = ptr(self.obj_num_tris)
         s.num_objects = len(self.obj_first_tri)
-        s.obj_orient = ptr(self.obj_orient)
-        s.obj_bbmin = ptr(self.obj_bbmin); s.obj_bbmax = ptr(self.obj_bbmax)
+        s.tri_orient = ptr(self.tri_orient)
+        s.tri_bbmin = ptr(self.tri_bbmin); s.tri_bbmax = ptr(self.tri_bbmax)
         s.mat_color = ptr(self.mat_color); s.mat_tex = ptr(self.mat_tex)
         s.num_materials = len(self.mat_tex)
         s.tex_data = ptr(self.tex_data); s.tex_offset = ptr(self.tex_offset)
@@ -421,6 +442,9 @@ class FlatScene:
         znear = _f32(RT_ZNEAR if self.raytracer else RASTER_ZNEAR)
         s.inv_near = _f32(1.0) / znear
         s.inv_far = (_f32(1.0) / _f32(RT_ZFAR)) if self.raytracer else _f32(0.0)
+        th = float(np.float32(math.tan(VFOV_DEG * math.pi / 360.0)))
+        asp = float(self.width) / float(self.height)
+        s.s6b_pad = _f32(float(znear) * math.sqrt(1.0 + th * th * (1.0 + asp * asp)) * 1.001)
         tl = to_light_vector()
         s.to_light = (ctypes.c_float * 3)(*[float(x) for x in tl])
         s.ambient = AMBIENT

@@ -47,11 +47,12 @@ typedef struct {
     const int32_t *obj_first_tri;  /* [O]                                     */
     const int32_t *obj_num_tris;   /* [O]                                     */
     int32_t        num_objects;
-    /* S6b: +1 / -1 for closed, consistently wound meshes (volume sign), else 0;
-     * padded object-space bounding box */
-    const float   *obj_orient;     /* [O]                                     */
-    const float   *obj_bbmin;      /* [O][3]                                  */
-    const float   *obj_bbmax;      /* [O][3]                                  */
+    /* S6b, per triangle, of its shell (edge-connected component of the object):
+     * +1 / -1 for a closed, consistently wound shell (volume sign), else 0;
+     * the shell's padded object-space bounding box */
+    const float   *tri_orient;     /* [T]                                     */
+    const float   *tri_bbmin;      /* [T][3]                                  */
+    const float   *tri_bbmax;      /* [T][3]                                  */
     /* materials / textures */
     const float   *mat_color;      /* [M][rgba]                               */
     const int32_t *mat_tex;        /* [M] texture index, -1 = none            */
@@ -75,6 +76,7 @@ typedef struct {
     /* pixel -> ray constants, computed on the host */
     float sx, ox, sz, oz;
     float inv_near, inv_far;
+    float s6b_pad;                 /* S6b: reach of the near plane            */
     float to_light[3];             /* unit vector towards the light, world    */
     float ambient, diffuse;
     float default_color[4];        /* material for tri_mat == -1              */
@@ -159,22 +161,11 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
         for (int r = 0; r < 3; ++r)
             tv[r] = dot3(Rc[0][r], Rc[1][r], Rc[2][r], dt[0], dt[1], dt[2]);
 
-        /* S6b: eye in the instance's unscaled frame, q = Ri^T (c - t), against
-         * the object's padded bounding box scaled by s */
-        int cull_back = 0, cull_front = 0;
-        {
-            int outside = 0;
-            for (int r = 0; r < 3; ++r) {
-                const float qo = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]);
-                const float b0 = s->obj_bbmin[3 * obj + r] * sc[r];
-                const float b1 = s->obj_bbmax[3 * obj + r] * sc[r];
-                if (qo < fminf(b0, b1) || qo > fmaxf(b0, b1))
-                    outside = 1;
-            }
-            const float handed = s->obj_orient[obj] * ((sc[0] * sc[1]) * sc[2]);
-            cull_back = outside && handed > 0.0f;
-            cull_front = outside && handed < 0.0f;
-        }
+        /* S6b: the eye in the instance's unscaled frame, q = Ri^T (c - t) */
+        float qo[3];
+        for (int r = 0; r < 3; ++r)
+            qo[r] = -dot3(Ri[0][r], Ri[1][r], Ri[2][r], dt[0], dt[1], dt[2]);
+        const float det = (sc[0] * sc[1]) * sc[2];   /* mirroring flips the winding */
         const int first = s->obj_first_tri[obj];
         const int cnt = s->obj_num_tris[obj];
         for (int ti = first; ti < first + cnt; ++ti, ++k) {
@@ -198,8 +189,21 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
             const float d = dot3(nn[0], nn[1], nn[2], P[0][0], P[0][1], P[0][2]);
             if (!(fabsf(d) > 0.0f))
                 continue;                                   /* S6: cull */
-            if ((cull_back && d > 0.0f) || (cull_front && d < 0.0f))
-                continue;                                   /* S6b */
+            {
+                /* S6b: eye outside the shell's padded box (scaled by s) by more
+                 * than the reach of the near plane -> faces turned away from it
+                 * can never be the nearest hit */
+                int outside = 0;
+                for (int r = 0; r < 3; ++r) {
+                    const float b0 = s->tri_bbmin[3 * ti + r] * sc[r];
+                    const float b1 = s->tri_bbmax[3 * ti + r] * sc[r];
+                    if (qo[r] < fminf(b0, b1) - s->s6b_pad || qo[r] > fmaxf(b0, b1) + s->s6b_pad)
+                        outside = 1;
+                }
+                const float handed = s->tri_orient[ti] * det;
+                if (outside && ((handed > 0.0f && d > 0.0f) || (handed < 0.0f && d < 0.0f)))
+                    continue;
+            }
             orc_tri *o = &out[n++];
             const float flip = d < 0.0f ? -1.0f : 1.0f;
             for (int e = 0; e < 3; ++e) {

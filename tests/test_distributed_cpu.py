@@ -34,8 +34,10 @@ def _worker(rank, world_size, port, num_worlds, out_dir):
     mine = scenes.synthetic_scene(hi - lo, with_wall=True, first_world=lo)
     # ... which is the same as slicing the whole job's description
     whole = scenes.synthetic_scene(num_worlds, with_wall=True)
-    assert mine.instances == whole.shard(rank, world_size).instances[:len(mine.instances)] \
-        or mine.cameras == whole.cameras[lo:hi]
+    n_inst = whole.worlds[0][0]
+    assert mine.instances == whole.instances[lo * n_inst:hi * n_inst]
+    assert mine.cameras == whole.cameras[lo:hi]
+    assert [w[0::2] for w in mine.worlds] == [w[0::2] for w in whole.shard(rank, world_size).worlds]
     o = oracle.FlatScene(mine).render(num_threads=2)
     counts = [b - a for a, b in sharding.view_ranges(whole.worlds, world_size)]
     rgb = sharding.gather_slabs(torch.from_numpy(o["rgb"]), counts)

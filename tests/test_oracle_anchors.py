@@ -208,13 +208,65 @@ def test_two_sided_coverage_and_light_direction(oracle_mod):
 def test_closed_mesh_detection(oracle_mod):
     cube, _ = oracle_mod.parse_obj(CUBE)
     plane, _ = oracle_mod.parse_obj(PLANE)
-    assert oracle_mod.closed_orientation(cube) == 1.0
-    assert oracle_mod.closed_orientation(plane) == 0.0            # open
-    assert oracle_mod.closed_orientation(cube[:, ::-1]) == -1.0   # inward winding
-    assert oracle_mod.closed_orientation(cube[:-1]) == 0.0        # a hole
+
+    def orient(tris):
+        return oracle_mod.shell_orientation(tris)[0].tolist()
+    assert orient(cube) == [1.0] * 12
+    assert orient(plane) == [0.0] * 2                             # open
+    assert orient(cube[:, ::-1]) == [-1.0] * 12                   # inward winding
+    assert orient(cube[:-1]) == [0.0] * 11                        # a hole
     mixed = cube.copy()
     mixed[0] = mixed[0, ::-1]                                     # one flipped face
-    assert oracle_mod.closed_orientation(mixed) == 0.0
+    assert orient(mixed) == [0.0] * 12
+    # two shells in one object, wound oppositely: each is judged on its own
+    # and carries its own bounding box
+    far = cube[:, ::-1] + np.float32(5.0)
+    o, lo, hi = oracle_mod.shell_orientation(np.concatenate([cube, far, plane]))
+    assert o.tolist() == [1.0] * 12 + [-1.0] * 12 + [0.0] * 2
+    assert np.all(hi[:12] < 1.0) and np.all(lo[12:24] > 4.0)
+
+
+def test_two_shells_of_opposite_winding_render_like_two_sided(oracle_mod, monkeypatch):
+    # one orientation per object culled the near faces of the
+    # minority shell.  Per-shell orientation must leave the image of a
+    # two-shell, mixed-winding object equal to the render without S6b.
+    cube, cuv = oracle_mod.parse_obj(CUBE)
+    shifted = cube[:, ::-1] + np.array([2.5, 0.0, 0.4], np.float32)
+    verts = np.concatenate([cube, shifted]).reshape(-1, 3)
+    d = scenes.SceneDesc(
+        num_worlds=1, width=64, height=64,
+        mesh_vertices=verts, mesh_uvs=np.zeros((len(verts), 2), np.float32),
+        mesh_indices=np.arange(len(verts), dtype=np.uint32),
+        mesh_vertex_offsets=np.array([0], np.uint32),
+        mesh_indices_offsets=np.array([0], np.uint32),
+        mesh_materials=np.array([-1], np.int32),
+        instances=[((-1.0, 6.0, 0.0), (0.9238795, 0.0, 0.0, 0.3826834), (1.5, 1.5, 1.5), 0)],
+        cameras=[((0.0, 0.0, 0.5), (1.0, 0.0, 0.0, 0.0))], worlds=[(1, 0, 1, 0)])
+    fs = oracle_mod.FlatScene(d)
+    assert fs.tri_orient.tolist() == [1.0] * 12 + [-1.0] * 12
+    with_cull = fs.render()
+    fs.tri_orient[:] = 0.0                  # S6b off: plain two-sided rule
+    without = fs.render()
+    assert (with_cull["tri_id"][0] >= 12).any() and (with_cull["tri_id"][0] >= 0).sum() > 100
+    assert np.array_equal(with_cull["rgb"], without["rgb"])
+    assert np.array_equal(with_cull["depth"], without["depth"])
+
+
+def test_back_faces_stay_when_the_near_plane_can_cut_the_front(oracle_mod):
+    # the eye sits just outside the cube's box, closer to its front face than
+    # znear (Raytracer: 0.1): the front face fails the near test, so the far
+    # wall must show -- culling it would leave background
+    ident = (1.0, 0.0, 0.0, 0.0)
+    d = _one_world([((0.0, 1.05, 0.0), ident, (2.0, 2.0, 2.0), 0)], [(CUBE, -1)],
+                   cam=((0.0, 0.0, 0.0), ident))
+    d.render_mode = "Raytracer"
+    fs = oracle_mod.FlatScene(d)
+    a = fs.render()
+    fs.tri_orient[:] = 0.0
+    b = fs.render()
+    assert np.array_equal(a["tri_id"], b["tri_id"]) and np.array_equal(a["depth"], b["depth"])
+    centre = a["depth"][0, 32, 32]
+    assert abs(centre - 2.05) < 1e-5          # the far wall (y = 2.05), not the near one (0.05)
 
 
 def test_back_faces_culled_outside_but_not_inside(oracle_mod):

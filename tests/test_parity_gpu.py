@@ -170,11 +170,63 @@ def test_config_c3_4096_worlds_128(native):
     assert_parity(got, ref)
 
 
-def test_pose_tensors_are_live_and_stepping_rerenders(native):
-    # scripts/test.py:137-151: mutate instance_position_tensor in place, step
+def test_config_c2_exactly_1024_worlds(native):
+    # BASELINE configs[1]: its own launch shape (two views per workgroup, 512
+    # workgroups, no XCD split)
+    desc = scenes.synthetic_scene(1024)
+    r = make_product(desc, visibility=True)
+    assert_parity(fetch(r), render_oracle(desc))
+
+
+def test_config_c4_last_shard_of_16384_worlds(native):
+    # BASELINE configs[3]: the rows rank 7 of 8 owns (worlds 14336 .. 16383)
+    desc = scenes.synthetic_scene(2048, first_world=7 * 2048)
+    whole_first = scenes.synthetic_scene(4, first_world=0)
+    assert desc.cameras[:4] != whole_first.cameras          # really other worlds
+    r = make_product(desc, visibility=False)
+    assert_parity(fetch(r, visibility=False), render_oracle(desc, want_ids=False))
+
+
+def test_config_c5_4096_worlds_256_textured_raytracer(native):
+    # BASELINE configs[4] at its full size: every pixel of every view, colour,
+    # depth and segmask (3 GiB of output on the card)
+    desc = scenes.synthetic_scene(4096, width=256, height=256, textured=True,
+                                  render_mode="Raytracer")
+    r = make_product(desc, visibility=False)
+    got = fetch(r, visibility=False, raytracer=True)
+    assert got["rgb"].shape == (4096, 256, 256, 4) and got["segmask"].dtype == np.int32
+    del r
+    ref = render_oracle(desc)
+    assert_parity(got, ref)
+    assert (ref["segmask"] >= 0).mean() > 0.6
+
+
+@pytest.mark.parametrize("own_stream", [False, True], ids=["null-stream", "torch-side-stream"])
+def test_pose_tensors_are_live_and_stepping_rerenders(native, own_stream):
+    # scripts/test.py:137-151: mutate instance_position_tensor in place, step --
+    # with NO host synchronisation between the write and step(): both are
+    # ordered on one stream (the null stream, or a torch side stream handed to
+    # the renderer with set_stream)
     import torch
     desc = scenes.demo_scene(num_worlds=4, render_mode="Rasterizer")
     r = make_product(desc)
+    if own_stream:
+        side = torch.cuda.Stream()
+        r.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            _pose_steps_and_check(r, busy=True)
+        return
+    _pose_steps_and_check(r)
+
+
+def _pose_steps_and_check(r, busy=False):
+    import torch
+    if busy:
+        # ~10 ms of work queued on the side stream ahead of the pose writes: a
+        # renderer still launching on the null stream would render stale poses
+        x = torch.randn(4096, 4096, device="cuda")
+        for _ in range(40):
+            x = (x @ x) * 1e-4
     pos = r.instance_position_tensor().to_torch()
     rot = r.instance_rotation_tensor().to_torch()
     cpos = r.camera_position_tensor().to_torch()
@@ -188,7 +240,6 @@ def test_pose_tensors_are_live_and_stepping_rerenders(native):
         pos[4][2] += 1.5
         pos[6][2] += 0.5
         cpos[1][0] -= 0.75
-        torch.cuda.synchronize()
         r.step()
     got = fetch(r)
     assert not np.array_equal(got["rgb"], before["rgb"])
@@ -317,6 +368,37 @@ def test_back_face_culling_cases(native):
     _, got, ref = _parity(d)
     assert got["rgb"].shape[0] == 8
     assert (got["tri_id"][1] >= 0).all()        # eye inside the cube: walls everywhere
+
+
+def test_back_face_culling_is_per_shell_and_respects_the_near_plane(native):
+    # an object of two shells wound oppositely (each judged on its
+    # own), and an eye outside a cube's box but within the near plane's reach
+    # of its front face (the far wall must show); the product must match the
+    # oracle AND the oracle must match its own render with S6b switched off
+    from oracle import oracle
+    cube, _ = oracle.parse_obj(CUBE)
+    shifted = cube[:, ::-1] + np.array([2.5, 0.0, 0.4], np.float32)
+    verts = np.concatenate([cube, shifted]).reshape(-1, 3)
+    for mode in ("Rasterizer", "Raytracer"):
+        d = scenes.SceneDesc(
+            num_worlds=2, width=64, height=64, render_mode=mode, asset_paths=[(CUBE, -1)],
+            mesh_vertices=verts, mesh_uvs=np.zeros((len(verts), 2), np.float32),
+            mesh_indices=np.arange(len(verts), dtype=np.uint32),
+            mesh_vertex_offsets=np.array([0], np.uint32),
+            mesh_indices_offsets=np.array([0], np.uint32),
+            mesh_materials=np.array([-1], np.int32),
+            instances=[((-1.0, 6.0, 0.0), (0.9238795, 0.0, 0.0, 0.3826834), (1.5, 1.5, 1.5), 1),
+                       ((0.0, 1.05, 0.0), IDENT, (2.0, 2.0, 2.0), 0)],
+            cameras=[((0.0, 0.0, 0.5), IDENT), ((0.0, 0.0, 0.0), IDENT)],
+            worlds=[(1, 0, 1, 0), (1, 1, 1, 1)])
+        _, got, ref = _parity(d)
+        fs = oracle.FlatScene(d)
+        fs.tri_orient[:] = 0.0
+        plain = fs.render()
+        assert np.array_equal(plain["rgb"], got["rgb"])
+        assert (got["tri_id"][0] >= 12).any()          # the inward-wound shell is visible
+        if mode == "Raytracer":
+            assert abs(got["depth"][1, 32, 32] - 2.05) < 1e-4
 
 
 def test_obj_materials_from_mtl(native, tmp_path):
