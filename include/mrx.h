@@ -116,7 +116,9 @@ typedef struct {
     /* build-only knobs (no counterpart in the reference) */
     void *stream;               /* hipStream_t to launch on; NULL = null stream */
     uint32_t flags;             /* MRX_FLAG_* */
-    int32_t kernel_variant;     /* 0 = default; see DESIGN.md section 5 */
+    int32_t kernel_variant;     /* 0 = default (raster kernels up to 256 triangles per
+                                 * world, BVH path above); 1 = brute-force cross-check;
+                                 * 2 = BVH path always; 3 = raster kernels always */
 } mrx_config;
 
 typedef struct mrx_renderer mrx_renderer;
@@ -146,6 +148,10 @@ typedef struct {
     int32_t device_id;
     int32_t kernel_variant;
     uint64_t bytes_per_step;        /* algorithmic HBM bytes of one render */
+    int32_t render_path;            /* 0 = tiled raster kernels, 1 = BVH ray-trace path */
+    uint32_t bvh_nodes;             /* 8-wide BLAS nodes of all objects     */
+    uint32_t bvh_depth;             /* deepest BLAS                         */
+    uint32_t max_world_instances;   /* most instances any one world holds   */
 } mrx_info_t;
 
 /* -- lifetime: replaces Manager::Manager / ~Manager (mgr.cpp:505-527).
@@ -210,6 +216,15 @@ int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width,
  *     "materials":[{"name":..,"kd":[r,g,b],"map_kd":..},...]} (materials = every
  *    newmtl of the file's mtllibs).  Returns the length, or a negative MRX_E_*. */
 int64_t mrx_describe_obj_materials(const char *path, char *json, uint64_t capacity);
+/*    Builds the bottom-level BVH of one triangle soup exactly as mrx_create does
+ *    for an object (the counterpart of AssetProcessor::makeBVHData,
+ *    /root/reference/src/mgr.cpp:472-473) and checks its invariants: every
+ *    triangle sits in exactly one leaf, every child box contains all that hangs
+ *    below it, leaves hold at most 16 triangles, the traversal stack bound
+ *    holds.  Returns MRX_OK or MRX_E_INVALID; counts are 0 for soups small
+ *    enough to need no hierarchy. */
+int mrx_blas_check(const float *tri_pos /*[T][9]*/, uint32_t num_tris, uint32_t *num_nodes,
+                   uint32_t *depth, uint32_t *num_leaves);
 void mrx_free(void *p);
 
 int mrx_device_count(void);

@@ -18,8 +18,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["raster.hip", "mrx_api.cpp", "assets.cpp"]
-HIP_DEPS = HIP_SOURCES + ["raster.hpp", "assets.hpp", "../../include/mrx.h"]
+HIP_SOURCES = ["raster.hip", "bvh.hip", "bvh.cpp", "mrx_api.cpp", "assets.cpp"]
+HIP_DEPS = HIP_SOURCES + ["raster.hpp", "raster_dev.hpp", "bvh.hpp", "assets.hpp",
+                          "../../include/mrx.h"]
 MGR_SOURCES = ["manager.cpp"]
 MGR_DEPS = MGR_SOURCES + ["../../include/madrona_mi355/manager.hpp",
                           "../../include/madrona_mi355/types.hpp", "../../include/mrx.h"]

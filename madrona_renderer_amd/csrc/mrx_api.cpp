@@ -16,6 +16,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "assets.hpp"
+#include "bvh.hpp"
 #include "raster.hpp"
 
 namespace {
@@ -175,7 +176,19 @@ struct mrx_renderer {
     DevBuf<float> depth;
     DevBuf<int32_t> ids;
     DevBuf<unsigned long long> stamps;
+    // BVH path: BLAS (built at load) and the tables the per-step TLAS reads
+    DevBuf<mrx::BvhNode> bvhNodes;
+    DevBuf<uint32_t> bvhLeafTris, worldInstStart, viewWorld, instKBase;
+    DevBuf<mrx::ObjInfo> objInfo;
+    bool useBvh = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    hipError_t launch()
+    {
+        if (useBvh)
+            return mrx::launchBvh(params, stream);
+        return mrx::launchRaster(params, info.max_world_triangles, variant, stream);
+    }
 
     ~mrx_renderer()
     {
@@ -185,6 +198,8 @@ struct mrx_renderer {
         instPos.release(); instRot.release(); instScale.release();
         camPos.release(); camRot.release(); instObj.release();
         rgb.release(); depth.release(); ids.release(); stamps.release();
+        bvhNodes.release(); bvhLeafTris.release(); worldInstStart.release();
+        viewWorld.release(); instKBase.release(); objInfo.release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
     }
@@ -436,8 +451,9 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     std::vector<float> instPos, instRot, instScale, camPos, camRot;
     std::vector<int32_t> instObj;
     std::vector<uint32_t> worldTriStart(1, 0), viewWorld;
+    std::vector<uint32_t> worldInstStart(1, 0), instKBase;
     std::vector<WorldTri> worldTris;   // per world; expanded per view below
-    uint32_t maxWorldTris = 0;
+    uint32_t maxWorldTris = 0, maxWorldInst = 0;
     for (uint32_t w = 0; w < cfg.num_worlds; ++w) {
         const mrx_world_init &wi = cfg.worlds[w];
         if ((uint64_t)wi.instances_offset + wi.num_instances > cfg.num_instances ||
@@ -451,6 +467,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             instRot.insert(instRot.end(), in.rotation, in.rotation + 4);
             instScale.insert(instScale.end(), in.scale, in.scale + 3);
             instObj.push_back(in.object_id);
+            // first world-local triangle index of the instance (the visibility id space)
+            instKBase.push_back((uint32_t)worldTris.size() - worldTriStart[w]);
             if (in.object_id >= 0 && (size_t)in.object_id < r.objFirst.size()) {
                 const uint32_t f = (uint32_t)r.objFirst[in.object_id];
                 const uint32_t n = (uint32_t)r.objCount[in.object_id];
@@ -459,6 +477,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             }
         }
         worldTriStart.push_back((uint32_t)worldTris.size());
+        worldInstStart.push_back((uint32_t)instObj.size());
+        maxWorldInst = std::max(maxWorldInst, wi.num_instances);
         const uint32_t nt = worldTriStart[w + 1] - worldTriStart[w];
         maxWorldTris = nt > maxWorldTris ? nt : maxWorldTris;
         for (uint32_t c = 0; c < wi.num_cameras; ++c) {
@@ -474,18 +494,43 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     MRX_HIP(r.triMats.upload(triMats));
     MRX_HIP(r.textures.upload(texDescs));
     MRX_HIP(r.texels.upload(texels));
-    // per-view draw lists with a fixed stride (one load level in the kernel)
+    // Which kernel renders: worlds of more triangles than the group kernel has
+    // slots (256) go through the BVH path (bvh.hip), in both render modes.
+    // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH
+    // / the raster kernels.
+    uint32_t bvhMinTris = 257;
+    if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
+        bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
+    r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);
+    // per-view draw lists with a fixed stride (one load level in the kernel);
+    // the BVH path walks the world's instances instead and needs none
     const uint32_t stride = maxWorldTris ? maxWorldTris : 1u;
-    std::vector<WorldTri> viewTris((size_t)viewWorld.size() * stride, WorldTri { 0, 0 });
-    std::vector<uint32_t> viewTriCount(viewWorld.size());
-    for (size_t v = 0; v < viewWorld.size(); ++v) {
-        const uint32_t w = viewWorld[v];
-        const uint32_t b = worldTriStart[w], n = worldTriStart[w + 1] - b;
-        viewTriCount[v] = n;
-        std::memcpy(viewTris.data() + v * stride, worldTris.data() + b, n * sizeof(WorldTri));
+    {
+        const size_t nv = r.useBvh ? 0 : viewWorld.size();
+        std::vector<WorldTri> viewTris(nv * stride, WorldTri { 0, 0 });
+        std::vector<uint32_t> viewTriCount(nv);
+        for (size_t v = 0; v < nv; ++v) {
+            const uint32_t w = viewWorld[v];
+            const uint32_t b = worldTriStart[w], n = worldTriStart[w + 1] - b;
+            viewTriCount[v] = n;
+            std::memcpy(viewTris.data() + v * stride, worldTris.data() + b, n * sizeof(WorldTri));
+        }
+        MRX_HIP(r.viewTris.upload(viewTris));
+        MRX_HIP(r.viewTriCount.upload(viewTriCount));
     }
-    MRX_HIP(r.viewTris.upload(viewTris));
-    MRX_HIP(r.viewTriCount.upload(viewTriCount));
+    // BLAS per object (the reference builds them at load too: mgr.cpp:472-473)
+    BlasSet blas;
+    buildBlas(tris.data(), r.objFirst, r.objCount, blas);
+    if (blas.leafTris.size() >= (1u << kBvhLeafStartBits))
+        return fail(MRX_E_UNSUPPORTED, "too many triangles in BLAS leaves");
+    if (blas.objects.empty())
+        blas.objects.emplace_back();                  // the kernel reads entry 0 for idle lanes
+    MRX_HIP(r.bvhNodes.upload(blas.nodes));
+    MRX_HIP(r.bvhLeafTris.upload(blas.leafTris));
+    MRX_HIP(r.objInfo.upload(blas.objects));
+    MRX_HIP(r.worldInstStart.upload(worldInstStart));
+    MRX_HIP(r.viewWorld.upload(viewWorld));
+    MRX_HIP(r.instKBase.upload(instKBase));
     MRX_HIP(r.instPos.upload(instPos));
     MRX_HIP(r.instRot.upload(instRot));
     MRX_HIP(r.instScale.upload(instScale));
@@ -617,6 +662,18 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.debugSlots = 0;
     if (const char *dbg = std::getenv("MRX_DEBUG_SLOTS"))
         p.debugSlots = std::atoi(dbg);
+    p.bvhNodes = r.bvhNodes.ptr;
+    p.bvhLeafTris = r.bvhLeafTris.ptr;
+    p.objInfo = r.objInfo.ptr;
+    p.numObjects = (uint32_t)r.objFirst.size();
+    p.worldInstStart = r.worldInstStart.ptr;
+    p.viewWorld = r.viewWorld.ptr;
+    p.instKBase = r.instKBase.ptr;
+    // TLAS records of up to 128 instances stay in LDS at once (two workgroups
+    // per CU); larger worlds take several passes
+    p.bvhPassInst = std::min<uint32_t>(128u, std::max<uint32_t>(64u, (maxWorldInst + 63u) / 64u * 64u));
+    if (const char *dbg = std::getenv("MRX_BVH_PASS_INST"))
+        p.bvhPassInst = std::min<uint32_t>(512u, std::max<uint32_t>(64u, (uint32_t)std::atoi(dbg) / 64u * 64u));
 
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;
@@ -631,6 +688,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     inf.storage_slow = nslow;
     inf.device_id = r.device;
     inf.kernel_variant = r.variant;
+    inf.render_path = r.useBvh ? 1 : 0;
+    inf.bvh_nodes = (uint32_t)blas.nodes.size();
+    inf.bvh_depth = blas.maxDepth;
+    inf.max_world_instances = maxWorldInst;
     inf.bytes_per_step = (uint64_t)px * (wantIds ? 12u : 8u) +
                          44ull * inf.num_instances + 28ull * nviews;
     return MRX_OK;
@@ -681,9 +742,7 @@ static int choosePlacement(mrx_renderer *r)
         r->params.depth = c.depth.ptr;
         r->params.ids = wantIds ? c.ids.ptr : nullptr;
     };
-    auto launch = [&]() {
-        return mrx::launchRaster(r->params, r->info.max_world_triangles, r->variant, r->stream);
-    };
+    auto launch = [&]() { return r->launch(); };
     auto timeBatch = [&](int n, float &ms) -> hipError_t {
         hipError_t e = hipEventRecord(r->ev0, r->stream);
         for (int i = 0; i < n && e == hipSuccess; ++i)
@@ -850,7 +909,7 @@ int mrx_render(mrx_renderer *r)
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
     MRX_HIP(hipSetDevice(r->device));
-    MRX_HIP(mrx::launchRaster(r->params, r->info.max_world_triangles, r->variant, r->stream));
+    MRX_HIP(r->launch());
     return MRX_OK;
 }
 
@@ -991,7 +1050,7 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(hipEventRecord(r->ev0, r->stream));
     for (int i = 0; i < steps; ++i)
-        MRX_HIP(mrx::launchRaster(r->params, r->info.max_world_triangles, r->variant, r->stream));
+        MRX_HIP(r->launch());
     MRX_HIP(hipEventRecord(r->ev1, r->stream));
     MRX_HIP(hipEventSynchronize(r->ev1));
     MRX_HIP(hipEventElapsedTime(ms_total, r->ev0, r->ev1));
@@ -1118,6 +1177,82 @@ int64_t mrx_describe_obj_materials(const char *path, char *json, uint64_t capaci
         return fail(MRX_E_INVALID, "buffer too small");
     std::memcpy(json, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
+}
+
+int mrx_blas_check(const float *tri_pos, uint32_t num_tris, uint32_t *num_nodes, uint32_t *depth,
+                   uint32_t *num_leaves)
+{
+    if ((!tri_pos && num_tris) || !num_nodes || !depth || !num_leaves)
+        return fail(MRX_E_INVALID, "null argument");
+    using namespace mrx;
+    std::vector<ObjTri> tris(num_tris);
+    for (uint32_t t = 0; t < num_tris; ++t)
+        std::memcpy(tris[t].p, tri_pos + 9 * (size_t)t, 36);
+    BlasSet b;
+    buildBlas(tris.data(), { 0 }, { (int32_t)num_tris }, b);
+    *num_nodes = (uint32_t)b.nodes.size();
+    *depth = b.maxDepth;
+    *num_leaves = 0;
+    const ObjInfo &o = b.objects[0];
+    if (o.root < 0)
+        return num_tris <= kBvhFlatMax && b.nodes.empty() ? MRX_OK
+                                                          : fail(MRX_E_INVALID, "large object without a hierarchy");
+    if (1 + 7 * b.maxDepth > kBvhStackCap)
+        return fail(MRX_E_INVALID, "hierarchy too deep for the traversal stack");
+    std::vector<uint32_t> seen(num_tris, 0);
+    // (node, box that must contain everything below it)
+    struct Item { uint32_t node; float lo[3], hi[3]; };
+    std::vector<Item> todo;
+    {
+        Item root {};
+        root.node = (uint32_t)o.root;
+        std::memcpy(root.lo, o.bbMin, 12);
+        std::memcpy(root.hi, o.bbMax, 12);
+        todo.push_back(root);
+    }
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.node >= b.nodes.size())
+            return fail(MRX_E_INVALID, "child index out of range");
+        const BvhNode &n = b.nodes[it.node];
+        for (uint32_t c = 0; c < kBvhWidth; ++c) {
+            const uint32_t ref = n.child[c];
+            if (ref == kBvhEmpty)
+                continue;
+            for (int a = 0; a < 3; ++a)
+                if (n.bmin[c][a] < it.lo[a] || n.bmax[c][a] > it.hi[a])
+                    return fail(MRX_E_INVALID, "child box sticks out of its parent's");
+            if (ref & kBvhLeafBit) {
+                const uint32_t cnt = ((ref >> kBvhLeafStartBits) & 15u) + 1u;
+                const uint32_t start = ref & ((1u << kBvhLeafStartBits) - 1u);
+                if (cnt > kBvhLeafMax || start + cnt > b.leafTris.size())
+                    return fail(MRX_E_INVALID, "bad leaf");
+                ++*num_leaves;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint32_t t = b.leafTris[start + i];
+                    if (t >= num_tris || seen[t]++)
+                        return fail(MRX_E_INVALID, "triangle missing from or repeated in the leaves");
+                    for (int v = 0; v < 3; ++v)
+                        for (int a = 0; a < 3; ++a) {
+                            const float x = tris[t].p[3 * v + a];
+                            if (x < n.bmin[c][a] || x > n.bmax[c][a])
+                                return fail(MRX_E_INVALID, "triangle outside its leaf's box");
+                        }
+                }
+            } else {
+                Item ch {};
+                ch.node = ref;
+                std::memcpy(ch.lo, n.bmin[c], 12);
+                std::memcpy(ch.hi, n.bmax[c], 12);
+                todo.push_back(ch);
+            }
+        }
+    }
+    for (uint32_t t = 0; t < num_tris; ++t)
+        if (seen[t] != 1)
+            return fail(MRX_E_INVALID, "triangle missing from the leaves");
+    return MRX_OK;
 }
 
 void mrx_free(void *p) { std::free(p); }

@@ -7,6 +7,9 @@
 
 namespace mrx {
 
+struct BvhNode;
+struct ObjInfo;
+
 // Object-space triangle: 16 dwords, one 64-byte line.
 struct alignas(16) ObjTri {
     float p[9];      // 3 vertices x xyz
@@ -115,16 +118,35 @@ struct RasterParams {
     // Diagnostic only (MRX_DEBUG_STAMPS=1): per-wave s_memrealtime stamps,
     // [workgroup][wave][8], written to memory nothing else reads.
     unsigned long long *debugStamps;
+    // ---- BVH path (bvh.hip): per-object BLAS built at load (bvh.hpp), the
+    //      world -> instance-row and view -> world tables the per-step TLAS is
+    //      built from, and each instance's first world-local triangle index
+    const BvhNode *bvhNodes;
+    const uint32_t *bvhLeafTris;
+    const ObjInfo *objInfo;          // [numObjects], at least one entry
+    uint32_t numObjects;
+    const uint32_t *worldInstStart;  // [worlds + 1]
+    const uint32_t *viewWorld;       // [views]
+    const uint32_t *instKBase;       // [I]
+    uint32_t bvhPassInst;            // instances whose TLAS records fit LDS at once (multiple of 64)
 };
 
 // Kernel variants (mrx_config.kernel_variant).
 enum KernelVariant : int32_t {
-    kVariantDefault = 0,
+    kVariantDefault = 0,     // group kernel up to kBvhMinTris-1 triangles per world, BVH above
     kVariantBrute = 1,       // v1: every triangle tested at every pixel
+    kVariantBvh = 2,         // BVH path whatever the scene size
+    kVariantRaster = 3,      // never the BVH path (group kernel, chunked kernel above 256)
     kNumVariants
 };
 
 hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
                         int32_t variant, hipStream_t stream);
+
+// BVH path: per-step TLAS in LDS, wave-packet traversal of TLAS + BLAS,
+// exact S6 leaf test (bvh.hip).  p.bvhPassInst is filled in by the caller.
+hipError_t launchBvh(const RasterParams &p, hipStream_t stream);
+// dynamic LDS bytes one workgroup of the BVH kernel needs for `passInst` instance records
+size_t bvhLdsBytes(uint32_t passInst, bool textured);
 
 }  // namespace mrx

@@ -1,0 +1,113 @@
+"""Procedural meshes and many-instance worlds for the BVH-path tests: the
+reference ships only 12-triangle assets (data/*.obj), so the large worlds the
+ray-trace path exists for (BASELINE configs[4]) are
+generated here, deterministically."""
+import math
+import os
+
+import numpy as np
+
+from madrona_renderer_amd import scenes
+
+CUBE = os.path.join(scenes.DATA_DIR, "cube.obj")
+PLANE = os.path.join(scenes.DATA_DIR, "plane.obj")
+IDENT = (1.0, 0.0, 0.0, 0.0)
+
+
+def grid_mesh(nu, nv, fn):
+    """(verts [N,3], uvs [N,2], indices [K]) of a (nu x nv)-quad parametric
+    surface fn(u, v) -> xyz with u, v in [0, 1]; two triangles per quad."""
+    us, vs = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    verts = np.asarray([fn(u, v) for u, v in zip(us.ravel(), vs.ravel())], np.float32)
+    uvs = np.stack([us.ravel() * 4.0, vs.ravel() * 4.0], axis=1).astype(np.float32)
+    idx = []
+    for i in range(nu):
+        for j in range(nv):
+            a = i * (nv + 1) + j
+            b, c, d = a + 1, a + nv + 1, a + nv + 2
+            idx += [a, c, b, b, c, d]
+    return verts, uvs, np.asarray(idx, np.uint32)
+
+
+def sphere(nu=32, nv=16, r=1.0):
+    def f(u, v):
+        th, ph = 2 * math.pi * u, math.pi * v
+        return (r * math.sin(ph) * math.cos(th), r * math.sin(ph) * math.sin(th), r * math.cos(ph))
+    return grid_mesh(nu, nv, f)
+
+
+def torus(nu=48, nv=24, R=2.0, r=0.7):
+    def f(u, v):
+        th, ph = 2 * math.pi * u, 2 * math.pi * v
+        return ((R + r * math.cos(ph)) * math.cos(th), (R + r * math.cos(ph)) * math.sin(th),
+                r * math.sin(ph))
+    return grid_mesh(nu, nv, f)
+
+
+def terrain(n=48, size=30.0, seed=5):
+    rng = np.random.default_rng(seed)
+    k = rng.uniform(0.5, 3.0, size=(4, 2))
+    ph = rng.uniform(0, 6.28, size=4)
+
+    def f(u, v):
+        x, y = (u - 0.5) * size, (v - 0.5) * size
+        z = sum(0.6 * math.sin(k[i, 0] * x * 0.4 + k[i, 1] * y * 0.4 + ph[i]) for i in range(4))
+        return (x, y, z)
+    return grid_mesh(n, n, f)
+
+
+def pack_meshes(meshes):
+    """[(verts, uvs, indices, material)] -> the raw-geometry kwargs of SceneDesc."""
+    verts, uvs, idx, voff, ioff, mats = [], [], [], [], [], []
+    nv = ni = 0
+    for v, t, i, m in meshes:
+        voff.append(nv)
+        ioff.append(ni)
+        verts.append(v)
+        uvs.append(t)
+        idx.append(i)
+        mats.append(m)
+        nv += len(v)
+        ni += len(i)
+    return dict(mesh_vertices=np.concatenate(verts).astype(np.float32),
+                mesh_uvs=np.concatenate(uvs).astype(np.float32),
+                mesh_indices=np.concatenate(idx).astype(np.uint32),
+                mesh_vertex_offsets=np.asarray(voff, np.uint32),
+                mesh_indices_offsets=np.asarray(ioff, np.uint32),
+                mesh_materials=np.asarray(mats, np.int32))
+
+
+def random_quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return tuple(float(np.float32(x)) for x in q)
+
+
+def cube_field(num_worlds, cubes, width=64, height=64, mode="Rasterizer", textured=False,
+               seed=1, spread=9.0, first_world=0):
+    """`cubes` cubes scattered over the ground plane of every world (12 * cubes
+    + 2 triangles per world), one camera per world on a ring -- the many-instance
+    shape of worlds the reference's TLAS is for.  Worlds differ (own rows)."""
+    mats = [((0.9, 0.7, 0.5, 1.0), 0 if textured else -1, 0.5, 0.5), ((0.3, 0.6, 0.3, 1.0), -1, 0.5, 0.5)]
+    inst, cams, worlds = [], [], []
+    for w in range(first_world, first_world + num_worlds):
+        rng = np.random.default_rng(seed * 100003 + w)
+        i0 = len(inst)
+        inst.append(((0.0, 0.0, 0.0), IDENT, (1.0, 1.0, 1.0), 1))
+        for _ in range(cubes):
+            p = rng.uniform(-spread, spread, 2)
+            s = float(rng.uniform(0.4, 1.3))
+            th = float(rng.uniform(0, 2 * math.pi))
+            inst.append(((float(np.float32(p[0])), float(np.float32(p[1])), float(np.float32(0.5 * s))),
+                         tuple(float(np.float32(x)) for x in (math.cos(th / 2), 0, 0, math.sin(th / 2))),
+                         (float(np.float32(s)),) * 3, 0))
+        az = float(rng.uniform(0, 2 * math.pi))
+        r, h = float(rng.uniform(11, 17)), float(rng.uniform(3, 9))
+        eye = tuple(float(np.float32(x)) for x in (r * math.cos(az), r * math.sin(az), h))
+        cams.append((eye, scenes.look_at(eye, (0.0, 0.0, 0.5))))
+        worlds.append((cubes + 1, i0, 1, len(cams) - 1))
+    return scenes.SceneDesc(
+        num_worlds=num_worlds, render_mode=mode, width=width, height=height,
+        asset_paths=[(CUBE, 0), (PLANE, 1)], materials=mats,
+        texture_paths=[os.path.join(scenes.DATA_DIR, "cube.png")],
+        instances=inst, cameras=cams, worlds=worlds)
