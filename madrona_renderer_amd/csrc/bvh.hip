@@ -42,12 +42,7 @@ constexpr int kBvhWaves = 8;            // one wave per 64x8 strip of the tile
 constexpr int kQueueCap = 64 + 32;      // a flush takes 64; one append adds <= 32
 constexpr int kInstRecDw = 24;          // MV[9] tv[3] qo[3] det sc[3] obj kBase firstTri numTris root
 
-struct WaveScratch {
-    float planes[kWave][16];            // A0 A1 A2 Dx | B0 B1 B2 Dy | C0 C1 C2 Dc | k - - -
-    uint2 queue[kQueueCap];             // (instance of the pass, object triangle)
-    uint32_t stack[kBvhStackCap];
-};
-static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch alignment");
+constexpr uint32_t kRootFlag = 0x40000000u;  // stack entry: the root node of an instance's BLAS
 
 struct Rect { float x0, x1, y0, y1; };  // storage pixels (fast, slow), inclusive
 
@@ -99,35 +94,64 @@ __device__ __forceinline__ Rect finishRect(const RasterParams &p, float x0, floa
     return r;
 }
 
-// One pixel of the lane against one triangle; ties in 1/depth go to the lower
-// world-local triangle index (what the oracle's in-order scan with a strict
-// '>' does), so the result does not depend on the traversal order.  `key` is
-// (triangle index << 6 | slot of the batch): one register carries both the
-// tie-break and where the winner's shading data sits; `changed` collects one
-// bit per pixel of the lane whose winner is of the current batch.
-constexpr int kSlotBits = 6;
-__device__ __forceinline__ void pixelTestTie(const PlanePairs &q, f32x2 r01, f32x2 r2d, float px,
-                                             float invNear, int32_t keyv, uint32_t bit, float &best,
-                                             int32_t &key, uint32_t &changed)
+// ---------------------------------------------------------------------------
+// The tile's depth buffer lives in LDS: one 64-bit word per pixel,
+//   high 32 bits  1/depth of the nearest hit so far (a positive float: its bit
+//                 pattern orders like the value)
+//   low 32 bits   (~k & 0x1FFFFF) << 10 | slot   -- k the world-local triangle
+//                 index, slot where the winner's shading record sits (never 0
+//                 and never 0xFFFFFFFF: worlds hold fewer than 2^21 - 1 triangles)
+// and every path merges into it with one ds_max_u64: a larger 1/depth wins, and
+// among equal 1/depth the LOWER triangle index -- the total order the oracle's
+// in-order scan with a strict '>' induces, so the result does not depend on
+// the order the hierarchy is walked in.  A low word of 0 means "no hit".
+// ---------------------------------------------------------------------------
+constexpr int kSlotBits = 10;
+constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr int kBigRound = 8;                    // in-wave fallback: large triangles per round
+constexpr int kBigCap = 96;                     // shared list of large triangles per round of the tile
+constexpr int kSmallAreaDefault = 32;           // pixels of (trimmed) bounding box
+
+template <bool TEX> constexpr int tabCap() { return TEX ? 256 : 1024; }
+
+struct WaveScratch {
+    // (instance of the pass, object triangle).  Once a batch is set up, the
+    // first 64 entries double as eight plane records for the in-wave fallback
+    // of the large-triangle pass.
+    uint2 queue[kQueueCap];
+    uint32_t stack[kBvhStackCap];
+};
+static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch alignment");
+static_assert(kBigRound * 64 <= kWave * 8, "fallback records alias the consumed part of the queue");
+
+__device__ __forceinline__ unsigned long long packHit(float it, uint32_t low)
+{
+    return ((unsigned long long)__float_as_uint(it) << 32) | low;
+}
+
+// One pixel of the lane against one (large) triangle of the round.
+__device__ __forceinline__ void pixelTestKey(const PlanePairs &q, f32x2 r01, f32x2 r2d, float px,
+                                             float invNear, uint32_t lowv, float &best, uint32_t &low)
 {
     const f32x2 pp = { px, px };
     const f32x2 e01 = fma2(q.A01, pp, r01);       // e0, e1
     const f32x2 e2d = fma2(q.A2D, pp, r2d);       // e2, 1/depth
     const float it = e2d.y;
-    const bool closer = (it > best) | ((it == best) & (keyv < key));
+    const bool closer = (it > best) | ((it == best) & (lowv > low));
     const bool in = (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f) & closer & (it <= invNear);
     best = in ? it : best;
-    key = in ? keyv : key;
-    changed |= in ? bit : 0u;
+    low = in ? lowv : low;
 }
 
 // IDS: 0 = no id tensor, 1 = visibility ids (world-local triangle index),
 // 2 = segmask (objectID of the winner's instance)
 template <int IDS, bool TEX>
 __global__ __launch_bounds__(kWave *kBvhWaves, 4)
-void bvhTraceKernel(const RasterParams p)
+void bvhTileKernel(const RasterParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int kCap = tabCap<TEX>();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
     const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
@@ -135,18 +159,19 @@ void bvhTraceKernel(const RasterParams p)
     const uint32_t tile = blockIdx.x - view * tilesPerView;
     const uint32_t tileX0 = (tile % p.tilesFast) * 64u, tileY0 = (tile / p.tilesFast) * 64u;
     const uint32_t passInst = p.bvhPassInst;
+    if (p.debugSkip & 16u)
+        return;                                       // timing aid: bare launch
 
-    // ---- LDS: TLAS of the pass (instance records, rectangles, 64-instance node
-    //      rectangles), then the per-wave scratch
-    float *instRec = reinterpret_cast<float *>(smem);
+    // ---- LDS: depth buffer of the tile, shading records of the pass, control
+    //      words, the TLAS of the pass, per-wave scratch
+    unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [64][64]
+    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + 4096);                         // [kCap] rgba tex obj k
+    float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [4]
+    float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 4);                   // [kBigCap] planes, key, box
+    float *instRec = reinterpret_cast<float *>(bigList + kBigCap);                      // [passInst][24]
     float4 *instRect = reinterpret_cast<float4 *>(instRec + (size_t)passInst * kInstRecDw);
-    float4 *chunkRect = instRect + passInst;
-    WaveScratch *ws = reinterpret_cast<WaveScratch *>(chunkRect + passInst / kWave) + wave;
-    float (*coldLds)[kCold] = nullptr;
-    if (TEX)
-        coldLds = reinterpret_cast<float (*)[kCold]>(
-                      reinterpret_cast<WaveScratch *>(chunkRect + passInst / kWave) + kBvhWaves) +
-                  wave * kWave;
+    WaveScratch *ws = reinterpret_cast<WaveScratch *>(instRect + passInst) + wave;
 
     // ---- view constants (wave-uniform)
     ViewConst vc;
@@ -160,66 +185,84 @@ void bvhTraceKernel(const RasterParams p)
                             p.toLight[0], p.toLight[1], p.toLight[2]);
         }
     }
-    const uint32_t world = p.viewWorld[view];
-    const uint32_t i0 = p.worldInstStart[world], i1 = p.worldInstStart[world + 1];
+    // (uniform worlds: arithmetic instead of two dependent loads)
+    uint32_t i0, i1;
+    if (p.bvhUniInst) {
+        uint32_t world = view;
+        if (p.bvhUniCams != 1)
+            world = view / p.bvhUniCams;
+        i0 = world * p.bvhUniInst;
+        i1 = i0 + p.bvhUniInst;
+    } else {
+        const uint32_t world = p.viewWorld[view];
+        i0 = p.worldInstStart[world];
+        i1 = p.worldInstStart[world + 1];
+    }
     const float isx = __builtin_amdgcn_rcpf(p.sx), isz = __builtin_amdgcn_rcpf(p.sz);
     const float invNear = p.invNear, invFar = p.invFar;
+    const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + 63u);
+    const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + 63u);
+    const int smallArea = p.bvhSmallArea;
 
-    // ---- the wave's strip and the lane's pixels: four consecutive pixels of one
-    //      row in each 32-pixel half (one 16-byte store per tensor and half)
+    for (int i = threadIdx.x; i < 4096; i += kWave * kBvhWaves)
+        zbuf[i] = packHit(invFar, 0u);
+    if (threadIdx.x == 0)
+        ctrl[0] = ctrl[1] = ctrl[2] = 0u;          // records, waves that are done, large triangles
+
+    // the lane's pixels at output time: strip = wave, four consecutive pixels of
+    // one row in each 32-pixel half (one 16-byte store per tensor and half)
     const int lx = lane & 7, ly = lane >> 3;
-    const float SX0 = (float)tileX0, SX1 = (float)(tileX0 + 63u);
-    const float SY0 = (float)(tileY0 + 8u * wave), SY1 = (float)(tileY0 + 8u * wave + 7u);
-    const float py = (float)(tileY0 + 8u * wave + ly);
-    float best[2][kRegionBlocks];
-    int32_t key[2][kRegionBlocks], seg[2][kRegionBlocks];
     uint32_t rgba[2][kRegionBlocks];
-    uint32_t changed = 0;
+    int32_t seg[2][kRegionBlocks];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
-            best[hf][b] = invFar;
-            key[hf][b] = -1;
-            seg[hf][b] = -1;
             rgba[hf][b] = 0xFF000000u;
+            seg[hf][b] = -1;
         }
 
     for (uint32_t passBase = i0; passBase < i1; passBase += passInst) {
         const uint32_t n = min(passInst, i1 - passBase);
-        if (passBase != i0)
-            __syncthreads();                          // previous pass's TLAS fully consumed
-        // ---- phase I: the TLAS of this pass.  Lane = instance: transform (S2/S3),
-        //      S6b quantities, projected object box; 64 instances form one node.
-        for (uint32_t ch = (uint32_t)wave; ch * kWave < n; ch += kBvhWaves) {
-            const uint32_t li = ch * kWave + lane;
+        __syncthreads();                              // depth buffer initialised / previous TLAS consumed
+        // ---- phase I: the TLAS of this pass, in LDS.  Lane = (instance, corner of
+        //      its object's box): transform (S2/S3) and S6b quantities per
+        //      instance, one projected corner per lane, 8-lane reduction.
+        for (uint32_t base = (uint32_t)wave * 8u; base < n; base += kBvhWaves * 8u) {
+            const uint32_t li = base + (uint32_t)(lane >> 3);
+            const int corner = lane & 7;
             const bool has = li < n;
             const uint32_t row = passBase + (has ? li : 0u);
+            // the object's range, root and box were copied per instance at load: no
+            // load depends on another here (an instance whose object id is negative
+            // this step is hidden)
             const int32_t obj = p.instObj[row];
-            const bool okObj = has && obj >= 0 && (uint32_t)obj < p.numObjects;
-            const float4 *oi = reinterpret_cast<const float4 *>(p.objInfo + (okObj ? obj : 0));
+            const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + row);
             const float4 o0 = oi[0], omin = oi[1], omax = oi[2];
+            const bool okObj = has && obj >= 0;
             InstXform x;
             instanceTransform(p, vc, row, x);
-            float x0 = __builtin_inff(), x1 = -__builtin_inff(), z0 = x0, z1 = x1;
-            bool front = true;
-#pragma nounroll
-            for (int corner = 0; corner < 8; ++corner) {
-                float fx, fz;
-                bool f;
-                projectCorner(p, x.MV, x.tv, (corner & 1) ? omax.x : omin.x, (corner & 2) ? omax.y : omin.y,
-                              (corner & 4) ? omax.z : omin.z, isx, isz, fx, fz, f);
-                front = front && f;
-                x0 = fminf(x0, fx); x1 = fmaxf(x1, fx);
-                z0 = fminf(z0, fz); z1 = fmaxf(z1, fz);
+            float fx, fz;
+            bool f;
+            projectCorner(p, x.MV, x.tv, (corner & 1) ? omax.x : omin.x, (corner & 2) ? omax.y : omin.y,
+                          (corner & 4) ? omax.z : omin.z, isx, isz, fx, fz, f);
+            float x0 = fx, x1 = fx, z0 = fz, z1 = fz;
+            int fr = f ? 1 : 0;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                x0 = fminf(x0, __shfl_xor(x0, m));
+                x1 = fmaxf(x1, __shfl_xor(x1, m));
+                z0 = fminf(z0, __shfl_xor(z0, m));
+                z1 = fmaxf(z1, __shfl_xor(z1, m));
+                fr &= __shfl_xor(fr, m);
             }
-            Rect r = finishRect(p, x0, x1, z0, z1, front);
+            Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
             const uint32_t numTris = __float_as_uint(o0.y);
             if (!okObj || numTris == 0u) {            // nothing to draw: a rectangle nothing meets
                 r.x0 = r.y0 = __builtin_inff();
                 r.x1 = r.y1 = -__builtin_inff();
             }
-            if (has) {
+            if (has && corner == 0) {
                 float4 *dst = reinterpret_cast<float4 *>(instRec + (size_t)li * kInstRecDw);
                 dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
                 dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
@@ -229,222 +272,369 @@ void bvhTraceKernel(const RasterParams p)
                 dst[5] = make_float4(__uint_as_float(p.instKBase[row]), o0.x, o0.y, o0.z);
                 instRect[li] = make_float4(r.x0, r.x1, r.y0, r.y1);
             }
-            // the node over these 64 instances: union of their rectangles
-            float nx0 = r.x0, nx1 = r.x1, ny0 = r.y0, ny1 = r.y1;
-            if (!has) {
-                nx0 = ny0 = __builtin_inff();
-                nx1 = ny1 = -__builtin_inff();
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                nx0 = fminf(nx0, __shfl_xor(nx0, m));
-                nx1 = fmaxf(nx1, __shfl_xor(nx1, m));
-                ny0 = fminf(ny0, __shfl_xor(ny0, m));
-                ny1 = fmaxf(ny1, __shfl_xor(ny1, m));
-            }
-            if (lane == 0)
-                chunkRect[ch] = make_float4(nx0, nx1, ny0, ny1);
         }
         __syncthreads();
 
-        // ---- phase II: the wave walks TLAS and BLAS for its strip.  All control
-        //      flow below is wave-uniform.
-        const uint32_t numChunks = (n + kWave - 1) / kWave;
+        // ---- phase II: geometry.  The waves split the work by instance: flat
+        //      objects round-robin, the eight children of a BLAS root one per
+        //      wave.  All control flow of a wave is wave-uniform.
         uint32_t qCount = 0, sp = 0, chunk = 0, curInst = 0;
+        const uint32_t numChunks = (n + kWave - 1) / kWave;
         uint64_t instMask = 0;
         float sMV[3][3] = {}, sTv[3] = {};
-        bool done = false;
+        bool done = (p.debugSkip & 4u) != 0;          // timing aid: no traversal at all
+        bool reported = false;
         for (;;) {
-            while (qCount < (uint32_t)kWave && !done) {
-                if (sp > 0) {
-                    --sp;
-                    const uint32_t ref = rflu(ws->stack[sp]);
-                    if (ref & kBvhLeafBit) {
-                        // ---- leaf: its triangles join the queue
-                        const uint32_t cnt = ((ref >> kBvhLeafStartBits) & 15u) + 1u;
-                        const uint32_t start = ref & ((1u << kBvhLeafStartBits) - 1u);
-                        if ((uint32_t)lane < cnt)
-                            ws->queue[qCount + lane] = make_uint2(curInst, p.bvhLeafTris[start + lane]);
-                        qCount += cnt;
-                    } else {
-                        // ---- inner node: lane = (child, box corner)
-                        const BvhNode *nd = p.bvhNodes + ref;
-                        const int c = lane >> 3, corner = lane & 7;
-                        const uint32_t cref = nd->child[c];
-                        const float cx = (corner & 1) ? nd->bmax[c][0] : nd->bmin[c][0];
-                        const float cy = (corner & 2) ? nd->bmax[c][1] : nd->bmin[c][1];
-                        const float cz = (corner & 4) ? nd->bmax[c][2] : nd->bmin[c][2];
-                        float fx, fz;
-                        bool f;
-                        projectCorner(p, sMV, sTv, cx, cy, cz, isx, isz, fx, fz, f);
-                        float x0 = fx, x1 = fx, z0 = fz, z1 = fz;
-                        int fr = f ? 1 : 0;
+            // -- produce until this wave's share is exhausted or the record table is full
+            bool tableFull = false;
+            while (!tableFull) {
+                while (qCount < (uint32_t)kWave && !done) {
+                    if (sp > 0) {
+                        --sp;
+                        const uint32_t ref = rflu(ws->stack[sp]);
+                        if (ref & kBvhLeafBit) {
+                            // leaf: its triangles join the queue
+                            const uint32_t cnt = ((ref >> kBvhLeafStartBits) & 15u) + 1u;
+                            const uint32_t start = ref & ((1u << kBvhLeafStartBits) - 1u);
+                            if ((uint32_t)lane < cnt)
+                                ws->queue[qCount + lane] = make_uint2(curInst, p.bvhLeafTris[start + lane]);
+                            qCount += cnt;
+                        } else {
+                            // inner node: lane = (child, box corner)
+                            const bool isRoot = (ref & kRootFlag) != 0;
+                            const BvhNode *nd = p.bvhNodes + (ref & ~kRootFlag);
+                            const int c = lane >> 3, corner = lane & 7;
+                            const uint32_t cref = nd->child[c];
+                            const float cx = (corner & 1) ? nd->bmax[c][0] : nd->bmin[c][0];
+                            const float cy = (corner & 2) ? nd->bmax[c][1] : nd->bmin[c][1];
+                            const float cz = (corner & 4) ? nd->bmax[c][2] : nd->bmin[c][2];
+                            float fx, fz;
+                            bool f;
+                            projectCorner(p, sMV, sTv, cx, cy, cz, isx, isz, fx, fz, f);
+                            float x0 = fx, x1 = fx, z0 = fz, z1 = fz;
+                            int fr = f ? 1 : 0;
 #pragma unroll
-                        for (int m = 1; m < 8; m <<= 1) {
-                            x0 = fminf(x0, __shfl_xor(x0, m));
-                            x1 = fmaxf(x1, __shfl_xor(x1, m));
-                            z0 = fminf(z0, __shfl_xor(z0, m));
-                            z1 = fmaxf(z1, __shfl_xor(z1, m));
-                            fr &= __shfl_xor(fr, m);
+                            for (int m = 1; m < 8; m <<= 1) {
+                                x0 = fminf(x0, __shfl_xor(x0, m));
+                                x1 = fmaxf(x1, __shfl_xor(x1, m));
+                                z0 = fminf(z0, __shfl_xor(z0, m));
+                                z1 = fmaxf(z1, __shfl_xor(z1, m));
+                                fr &= __shfl_xor(fr, m);
+                            }
+                            const Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
+                            // the root's children are dealt one per wave
+                            const bool hit = cref != kBvhEmpty && corner == 0 && (!isRoot || c == wave) &&
+                                             overlaps(r, TX0, TX1, TY0, TY1);
+                            uint64_t hm = __ballot(hit);
+                            while (hm) {
+                                const int l = __builtin_ctzll(hm);
+                                hm &= hm - 1;
+                                ws->stack[sp++] = (uint32_t)__builtin_amdgcn_readlane((int)cref, l);
+                            }
                         }
-                        const Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
-                        const bool hit = cref != kBvhEmpty && corner == 0 && overlaps(r, SX0, SX1, SY0, SY1);
-                        uint64_t hm = __ballot(hit);
-                        while (hm) {
-                            const int l = __builtin_ctzll(hm);
-                            hm &= hm - 1;
-                            ws->stack[sp++] = (uint32_t)__builtin_amdgcn_readlane((int)cref, l);
-                        }
-                    }
-                } else if (instMask) {
-                    // ---- next instance of the TLAS node whose rectangle meets the strip
-                    const int b = __builtin_ctzll(instMask);
-                    instMask &= instMask - 1;
-                    curInst = (chunk - 1u) * kWave + (uint32_t)b;
-                    const float *rec = instRec + (size_t)curInst * kInstRecDw;
-                    const uint32_t first = rflu(__float_as_uint(rec[21]));
-                    const uint32_t num = rflu(__float_as_uint(rec[22]));
-                    const int32_t root = (int32_t)rflu(__float_as_uint(rec[23]));
-                    if (root < 0) {
-                        // flat object (<= kBvhFlatMax triangles): all of them
-                        if ((uint32_t)lane < num)
-                            ws->queue[qCount + lane] = make_uint2(curInst, first + lane);
-                        qCount += num;
-                    } else {
+                    } else if (instMask) {
+                        // next instance of this wave's share whose rectangle meets the tile
+                        const int b = __builtin_ctzll(instMask);
+                        instMask &= instMask - 1;
+                        curInst = (chunk - 1u) * kWave + (uint32_t)b;
+                        const float *rec = instRec + (size_t)curInst * kInstRecDw;
+                        const uint32_t first = rflu(__float_as_uint(rec[21]));
+                        const uint32_t num = rflu(__float_as_uint(rec[22]));
+                        const int32_t root = (int32_t)rflu(__float_as_uint(rec[23]));
+                        if (root < 0) {
+                            // flat object (<= kBvhFlatMax triangles): all of them
+                            if ((uint32_t)lane < num)
+                                ws->queue[qCount + lane] = make_uint2(curInst, first + lane);
+                            qCount += num;
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) {
+                            for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                            for (int cc = 0; cc < 3; ++cc)
-                                sMV[r][cc] = rfl(rec[3 * r + cc]);
-                            sTv[r] = rfl(rec[9 + r]);
+                                for (int cc = 0; cc < 3; ++cc)
+                                    sMV[r][cc] = rfl(rec[3 * r + cc]);
+                                sTv[r] = rfl(rec[9 + r]);
+                            }
+                            ws->stack[sp++] = (uint32_t)root | kRootFlag;
                         }
-                        ws->stack[sp++] = (uint32_t)root;
-                    }
-                } else if (chunk < numChunks) {
-                    // ---- next TLAS node (64 instances): lane = instance
-                    const float4 cr = chunkRect[chunk];
-                    Rect nr;
-                    nr.x0 = rfl(cr.x); nr.x1 = rfl(cr.y); nr.y0 = rfl(cr.z); nr.y1 = rfl(cr.w);
-                    if (overlaps(nr, SX0, SX1, SY0, SY1)) {
+                    } else if (chunk < numChunks) {
+                        // next 64 instances of the TLAS: lane = instance
                         const uint32_t li = chunk * kWave + lane;
                         const float4 ir = instRect[li < n ? li : 0u];
                         Rect r;
                         r.x0 = ir.x; r.x1 = ir.y; r.y0 = ir.z; r.y1 = ir.w;
-                        instMask = __ballot(li < n && overlaps(r, SX0, SX1, SY0, SY1));
+                        const bool hitI = li < n && overlaps(r, TX0, TX1, TY0, TY1);
+                        const bool blas = __float_as_int(instRec[(size_t)(li < n ? li : 0u) * kInstRecDw + 23]) >= 0;
+                        instMask = __ballot(hitI && (blas || (lane & (kBvhWaves - 1)) == wave));
+                        ++chunk;
+                    } else {
+                        done = true;
                     }
-                    ++chunk;
-                } else {
-                    done = true;
+                    waveLdsSync();
                 }
-                waveLdsSync();
-            }
-            if (qCount == 0)
-                break;
+                if (qCount == 0)
+                    break;
 
-            // ---- leaf test, 64 candidates at a time.  Lane = triangle: S3-S7 with
-            //      the instance's transform from the TLAS record.
-            const uint32_t nb = qCount < (uint32_t)kWave ? qCount : (uint32_t)kWave;
-            bool live = false;
-            uint32_t rgbaL = 0;
-            int32_t texL = -1, objL = -1;
-            float bbX0 = 0.f, bbX1 = 0.f;
-            if ((uint32_t)lane < nb) {
-                const uint2 e = ws->queue[lane];
-                const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)e.x * kInstRecDw);
-                const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4], a5 = rec[5];
-                InstXform x;
-                x.MV[0][0] = a0.x; x.MV[0][1] = a0.y; x.MV[0][2] = a0.z; x.MV[1][0] = a0.w;
-                x.MV[1][1] = a1.x; x.MV[1][2] = a1.y; x.MV[2][0] = a1.z; x.MV[2][1] = a1.w;
-                x.MV[2][2] = a2.x; x.tv[0] = a2.y; x.tv[1] = a2.z; x.tv[2] = a2.w;
-                x.qo[0] = a3.x; x.qo[1] = a3.y; x.qo[2] = a3.z; x.det = a3.w;
-                x.sc[0] = a4.x; x.sc[1] = a4.y; x.sc[2] = a4.z;
-                const int32_t obj = __float_as_int(a4.w);
-                const int32_t k = (int32_t)(__float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y)));
+                // -- a batch of up to 64 candidates: reserve shading records
+                const uint32_t nb = qCount < (uint32_t)kWave ? qCount : (uint32_t)kWave;
+                uint32_t slotBase = 0;
+                if (lane == 0)
+                    slotBase = atomicAdd(&ctrl[0], nb);
+                slotBase = rflu(slotBase);
+                if (slotBase + nb > (uint32_t)kCap) {
+                    tableFull = true;                 // wait for the resolve, then take the batch again
+                    break;
+                }
+                // -- leaf test setup.  Lane = triangle: S3-S7 with the instance's
+                //    transform from the TLAS record.
+                bool live = false;
                 TriPlanes c;
-                float shade[4], cold[kCold];
-                const bool valid = setupTriangleCore(p, vc.lv, x, e.y, obj, k, c, shade, cold);
-                live = valid && c.bbX1 >= SX0 && c.bbX0 <= SX1 && c.bbY1 >= SY0 && c.bbY0 <= SY1;
-                float4 *dst = reinterpret_cast<float4 *>(ws->planes[lane]);
-                dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
-                dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
-                dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
-                dst[3] = make_float4(__int_as_float((k << kSlotBits) | lane), 0.f, 0.f, 0.f);
-                rgbaL = __float_as_uint(shade[0]);
-                texL = __float_as_int(shade[1]);
-                objL = obj;
-                bbX0 = c.bbX0;
-                bbX1 = c.bbX1;
-                if (TEX && texL >= 0) {
+                c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
+                c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
+                c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
+                uint32_t lowKey = 0;
+                if ((uint32_t)lane < nb && !(p.debugSkip & 8u)) {
+                    const uint2 e = ws->queue[lane];
+                    const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)e.x * kInstRecDw);
+                    const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4], a5 = rec[5];
+                    InstXform x;
+                    x.MV[0][0] = a0.x; x.MV[0][1] = a0.y; x.MV[0][2] = a0.z; x.MV[1][0] = a0.w;
+                    x.MV[1][1] = a1.x; x.MV[1][2] = a1.y; x.MV[2][0] = a1.z; x.MV[2][1] = a1.w;
+                    x.MV[2][2] = a2.x; x.tv[0] = a2.y; x.tv[1] = a2.z; x.tv[2] = a2.w;
+                    x.qo[0] = a3.x; x.qo[1] = a3.y; x.qo[2] = a3.z; x.det = a3.w;
+                    x.sc[0] = a4.x; x.sc[1] = a4.y; x.sc[2] = a4.z;
+                    const int32_t obj = __float_as_int(a4.w);
+                    const uint32_t k = __float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y));
+                    float shade[4], cold[kCold];
+                    const bool valid = setupTriangleCore(p, vc.lv, x, e.y, obj, (int32_t)k, c, shade, cold);
+                    live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
+                    const uint32_t slot = slotBase + (uint32_t)lane;
+                    lowKey = ((~k & kKeyMask) << kSlotBits) | slot;
+                    if (live) {
+                        shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(obj), __uint_as_float(k));
+                        if (TEX && __float_as_int(shade[1]) >= 0) {
 #pragma unroll
-                    for (int i = 0; i < 9; ++i)
-                        coldLds[lane][i] = cold[i];
+                            for (int i = 0; i < 9; ++i)
+                                coldTab[slot][i] = cold[i];
+                        }
+                    }
+                }
+                // pixel range of the triangle inside the tile: the conservative box
+                // of setup, less all but 1/32 of its one-pixel margin
+                const float kTrim = 0.96875f;
+                const float fx0 = ceilf(fmaxf(c.bbX0 + kTrim, TX0)), fx1 = floorf(fminf(c.bbX1 - kTrim, TX1));
+                const float fy0 = ceilf(fmaxf(c.bbY0 + kTrim, TY0)), fy1 = floorf(fminf(c.bbY1 - kTrim, TY1));
+                live = live && fx0 <= fx1 && fy0 <= fy1;
+                const int ix0 = live ? (int)fx0 : 0, iy0 = live ? (int)fy0 : 0;
+                const int bw = live ? (int)fx1 - ix0 + 1 : 0, bh = live ? (int)fy1 - iy0 + 1 : 0;
+                const int area = bw * bh;
+                const bool small = live && area <= smallArea;
+                const bool big = live && !small;
+                if (!(p.debugSkip & 2u)) {
+                    // -- small triangles: the lane walks the pixels of its triangle's box
+                    {
+                        int pxi = ix0, pyi = iy0;
+                        const int cnt = (small && !(p.debugSkip & 32u)) ? area : 0;
+                        for (int i = 0; __ballot(i < cnt) != 0; ++i) {
+                            if (i < cnt) {
+                                const float px = (float)pxi, py = (float)pyi;
+                                const float e0 = __builtin_fmaf(c.A0, px, __builtin_fmaf(c.B0, py, c.C0));
+                                const float e1 = __builtin_fmaf(c.A1, px, __builtin_fmaf(c.B1, py, c.C1));
+                                const float e2 = __builtin_fmaf(c.A2, px, __builtin_fmaf(c.B2, py, c.C2));
+                                const float it = __builtin_fmaf(c.Dx, px, __builtin_fmaf(c.Dy, py, c.Dc));
+                                if (fminf(fminf(e0, e1), e2) >= 0.0f && it > invFar && it <= invNear)
+                                    atomicMax(&zbuf[(pyi - (int)tileY0) * 64 + (pxi - (int)tileX0)],
+                                              packHit(it, lowKey));
+                                ++pxi;
+                                if (pxi >= ix0 + bw) {
+                                    pxi = ix0;
+                                    ++pyi;
+                                }
+                            }
+                        }
+                    }
+                    // -- large triangles go on the tile's shared list: after the barrier all
+                    //    eight waves rasterise them, each its own strip
+                    uint64_t bigMask = __ballot(big && !(p.debugSkip & 64u));
+                    const int numBig = __builtin_popcountll(bigMask);
+                    const int rank = __builtin_popcountll(bigMask & ((1ull << lane) - 1ull));
+                    const uint32_t boxXY = (uint32_t)(ix0 - (int)tileX0) | ((uint32_t)(bw - 1) << 8) |
+                                           ((uint32_t)(iy0 - (int)tileY0) << 16) | ((uint32_t)(bh - 1) << 24);
+                    if (numBig) {
+                        uint32_t bigBase = 0;
+                        if (lane == 0)
+                            bigBase = atomicAdd(&ctrl[2], (uint32_t)numBig);
+                        bigBase = rflu(bigBase);
+                        if (bigBase + (uint32_t)numBig <= (uint32_t)kBigCap) {
+                            if ((bigMask >> lane) & 1ull) {
+                                float4 *dst = reinterpret_cast<float4 *>(bigList[bigBase + rank]);
+                                dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
+                                dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
+                                dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
+                                dst[3] = make_float4(__uint_as_float(lowKey), __uint_as_float(boxXY), 0.f, 0.f);
+                            }
+                            bigMask = 0;
+                        } else if (bigBase < (uint32_t)kBigCap && (uint32_t)lane < (uint32_t)kBigCap - bigBase) {
+                            // the reservation ran over the end of the list: blank what
+                            // it covers (the pass reads every entry below the count)
+                            reinterpret_cast<float4 *>(bigList[bigBase + lane])[3] =
+                                make_float4(0.f, __uint_as_float(0x00FF0000u), 0.f, 0.f);
+                        }
+                    }
+                    // -- the list is full (a close-up: most triangles are large): this wave
+                    //    rasterises its own, eight at a time, over the whole tile
+                    float (*ownPlanes)[16] = reinterpret_cast<float (*)[16]>(ws->queue);
+                    for (int round = 0; bigMask != 0 && round * kBigRound < numBig; ++round) {
+                        const bool mine = ((bigMask >> lane) & 1ull) && rank / kBigRound == round;
+                        waveLdsSync();
+                        if (mine) {
+                            float4 *dst = reinterpret_cast<float4 *>(ownPlanes[rank % kBigRound]);
+                            dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
+                            dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
+                            dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
+                            dst[3] = make_float4(__uint_as_float(lowKey), 0.f, 0.f, 0.f);
+                        }
+                        waveLdsSync();
+                        const uint64_t roundMask = __ballot(mine);
+                        for (int region = 0; region < 16; ++region) {
+                            const int strip = region >> 1, hf = region & 1;
+                            const int RX0 = (int)tileX0 + 32 * hf, RY0 = (int)tileY0 + 8 * strip;
+                            uint64_t act = __ballot(mine && ix0 <= RX0 + 31 && ix0 + bw > RX0 &&
+                                                    iy0 <= RY0 + 7 && iy0 + bh > RY0);
+                            if (act == 0)
+                                continue;
+                            float best[kRegionBlocks];
+                            uint32_t low[kRegionBlocks];
+#pragma unroll
+                            for (int b = 0; b < kRegionBlocks; ++b) {
+                                best[b] = invFar;
+                                low[b] = kNoHit;             // larger than any key: no tie with "nothing yet"
+                            }
+                            const float py = (float)(RY0 + ly);
+                            const f32x2 yy = { py, py };
+                            for (; act != 0; act &= act - 1) {
+                                const int l = __builtin_ctzll(act);
+                                const int ent = __builtin_popcountll(roundMask & ((1ull << l) - 1ull));
+                                const PlanePairs q = loadPlanes(ownPlanes, ent);
+                                const uint32_t lowv = rflu(__float_as_uint(ownPlanes[ent][12]));
+                                const f32x2 r01 = fma2(q.B01, yy, q.C01);
+                                const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
+#pragma unroll
+                                for (int b = 0; b < kRegionBlocks; ++b)
+                                    pixelTestKey(q, r01, r2d, (float)(RX0 + 4 * lx + b), invNear, lowv,
+                                                 best[b], low[b]);
+                            }
+                            unsigned long long *zrow = zbuf + (8 * strip + ly) * 64 + 32 * hf + 4 * lx;
+#pragma unroll
+                            for (int b = 0; b < kRegionBlocks; ++b)
+                                if (low[b] != kNoHit)
+                                    atomicMax(zrow + b, packHit(best[b], low[b]));
+                        }
+                    }
+                    waveLdsSync();
+                }
+                // -- what did not fit the batch moves to the front of the queue
+                if (qCount > (uint32_t)kWave) {
+                    const uint32_t rem = qCount - kWave;
+                    uint2 e = make_uint2(0u, 0u);
+                    if ((uint32_t)lane < rem)
+                        e = ws->queue[kWave + lane];
+                    waveLdsSync();
+                    if ((uint32_t)lane < rem)
+                        ws->queue[lane] = e;
+                    waveLdsSync();
+                    qCount = rem;
+                } else {
+                    qCount = 0;
                 }
             }
-            waveLdsSync();
+            if (done && qCount == 0 && !reported) {
+                reported = true;
+                if (lane == 0)
+                    atomicAdd(&ctrl[1], 1u);
+            }
+            __syncthreads();
+            // -- the round's large triangles: wave = strip, lane = entry for the box
+            //    test, then four pixels of the lane per 32-pixel half
+            {
+                const uint32_t listed = min(rflu(ctrl[2]), (uint32_t)kBigCap);
+                for (uint32_t e0 = 0; e0 < listed; e0 += kWave) {
+                    const uint32_t ent = e0 + (uint32_t)lane;
+                    const uint32_t box = ent < listed ? __float_as_uint(bigList[ent][13]) : 0u;
+                    const int bx0 = (int)(box & 255u), bx1 = bx0 + (int)((box >> 8) & 255u);
+                    const int by0 = (int)((box >> 16) & 255u), by1 = by0 + (int)(box >> 24);
+                    const bool rows = ent < listed && by0 <= 8 * wave + 7 && by1 >= 8 * wave;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const float HX0 = SX0 + 32.0f * hf;
-                uint64_t act = __ballot(live && bbX1 >= HX0 && bbX0 <= HX0 + 31.0f);
-                const f32x2 yy = { py, py };
-                for (; act != 0; act &= act - 1) {
-                    const int slot = __builtin_ctzll(act);
-                    const PlanePairs q = loadPlanes(ws->planes, slot);
-                    const int32_t keyv = (int32_t)rflu(__float_as_uint(ws->planes[slot][12]));
-                    const f32x2 r01 = fma2(q.B01, yy, q.C01);
-                    const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
+                    for (int hf = 0; hf < 2; ++hf) {
+                        uint64_t act = __ballot(rows && bx0 <= 32 * hf + 31 && bx1 >= 32 * hf);
+                        if (act == 0)
+                            continue;
+                        float best[kRegionBlocks];
+                        uint32_t low[kRegionBlocks];
 #pragma unroll
-                    for (int b = 0; b < kRegionBlocks; ++b)
-                        pixelTestTie(q, r01, r2d, (float)(tileX0 + hf * 32 + 4 * lx + b), invNear, keyv,
-                                     1u << (hf * kRegionBlocks + b), best[hf][b], key[hf][b], changed);
+                        for (int b = 0; b < kRegionBlocks; ++b) {
+                            best[b] = invFar;
+                            low[b] = kNoHit;
+                        }
+                        const float py = (float)(tileY0 + 8u * wave + ly);
+                        const f32x2 yy = { py, py };
+                        for (; act != 0; act &= act - 1) {
+                            const int l = (int)e0 + __builtin_ctzll(act);
+                            const PlanePairs q = loadPlanes(bigList, l);
+                            const uint32_t lowv = rflu(__float_as_uint(bigList[l][12]));
+                            const f32x2 r01 = fma2(q.B01, yy, q.C01);
+                            const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
+#pragma unroll
+                            for (int b = 0; b < kRegionBlocks; ++b)
+                                pixelTestKey(q, r01, r2d, (float)(tileX0 + 32 * hf + 4 * lx + b), invNear, lowv,
+                                             best[b], low[b]);
+                        }
+                        unsigned long long *zrow = zbuf + (8 * wave + ly) * 64 + 32 * hf + 4 * lx;
+#pragma unroll
+                        for (int b = 0; b < kRegionBlocks; ++b)
+                            if (low[b] != kNoHit)
+                                atomicMax(zrow + b, packHit(best[b], low[b]));
+                    }
                 }
             }
-            // ---- shade this batch's winners before its records are replaced: colour
-            //      and objectID come from the lane that set the winner up
+            __syncthreads();
+            // -- resolve: every lane looks its eight pixels up; winners whose record
+            //    is in the table of this round are shaded now (a later round reuses
+            //    the table)
+            const bool allDone = rflu(ctrl[1]) == (uint32_t)kBvhWaves;
+            if (threadIdx.x == 0)
+                ctrl[0] = ctrl[2] = 0u;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int b = 0; b < kRegionBlocks; ++b) {
-                    const bool has = (changed >> (hf * kRegionBlocks + b)) & 1u;
-                    const int32_t slot = key[hf][b] & ((1 << kSlotBits) - 1);
-                    const int src = (has ? slot : 0) << 2;
-                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rgbaL);
-                    rgba[hf][b] = has ? c0 : rgba[hf][b];
-                    if (IDS == 2) {
-                        const int32_t s0 = __builtin_amdgcn_ds_bpermute(src, objL);
-                        seg[hf][b] = has ? s0 : seg[hf][b];
-                    }
-                    if (TEX) {
-                        const int32_t tex = __builtin_amdgcn_ds_bpermute(src, texL);
-                        if (has && tex >= 0)
-                            rgba[hf][b] = shadeTextured(p, coldLds[slot], tex,
-                                                        (float)(tileX0 + hf * 32 + 4 * lx + b), py,
-                                                        1.0f / best[hf][b]);
+                    const unsigned long long z = zbuf[(8 * wave + ly) * 64 + 32 * hf + 4 * lx + b];
+                    const uint32_t low = (uint32_t)z;
+                    const uint32_t slot = low & ((1u << kSlotBits) - 1u);
+                    const uint32_t k = ~(low >> kSlotBits) & kKeyMask;
+                    const float4 rec = shadeTab[slot < (uint32_t)kCap ? slot : 0u];
+                    if (low != 0u && slot < (uint32_t)kCap && __float_as_uint(rec.w) == k) {
+                        rgba[hf][b] = __float_as_uint(rec.x);
+                        seg[hf][b] = __float_as_int(rec.z);
+                        const int32_t tex = __float_as_int(rec.y);
+                        if (TEX && tex >= 0)
+                            rgba[hf][b] = shadeTextured(p, coldTab[slot], tex,
+                                                        (float)(tileX0 + hf * 32 + 4 * lx + b),
+                                                        (float)(tileY0 + 8u * wave + ly),
+                                                        1.0f / __uint_as_float((uint32_t)(z >> 32)));
                     }
                 }
-            changed = 0;
-            waveLdsSync();
-            // ---- what did not fit the batch moves to the front of the queue
-            if (qCount > (uint32_t)kWave) {
-                const uint32_t rem = qCount - kWave;
-                uint2 e = make_uint2(0u, 0u);
-                if ((uint32_t)lane < rem)
-                    e = ws->queue[kWave + lane];
-                waveLdsSync();
-                if ((uint32_t)lane < rem)
-                    ws->queue[lane] = e;
-                waveLdsSync();
-                qCount = rem;
-            } else {
-                qCount = 0;
-            }
-            if (done && qCount == 0)
+            __syncthreads();
+            if (allDone)
                 break;
         }
+        if (threadIdx.x == 0)
+            ctrl[1] = 0u;                             // (ordered by the barrier that opens the next pass)
     }
+    __syncthreads();
 
     // ---- output: depth = 1/best (v_rcp_f32, <= 1 ulp), one 16-byte store per
     //      tensor and half
-    if (view >= p.numViews || (p.debugSkip & 1u))
+    if (p.debugSkip & 1u)
         return;
     const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
     const bool full = (p.nfast & 3u) == 0 && tileX0 + 64u <= p.nfast && tileY0 + 64u <= p.nslow;
@@ -456,8 +646,11 @@ void bvhTraceKernel(const RasterParams p)
         uint32_t dep[kRegionBlocks], id[kRegionBlocks];
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
-            dep[b] = key[hf][b] >= 0 ? __float_as_uint(__builtin_amdgcn_rcpf(best[hf][b])) : 0u;
-            id[b] = (uint32_t)(IDS == 2 ? seg[hf][b] : key[hf][b] >> kSlotBits);
+            const unsigned long long z = zbuf[(8 * wave + ly) * 64 + 32 * hf + 4 * lx + b];
+            const uint32_t low = (uint32_t)z;
+            dep[b] = low != 0u ? __float_as_uint(__builtin_amdgcn_rcpf(__uint_as_float((uint32_t)(z >> 32)))) : 0u;
+            id[b] = IDS == 2 ? (uint32_t)seg[hf][b]
+                             : (low != 0u ? (~(low >> kSlotBits) & kKeyMask) : 0xFFFFFFFFu);
         }
         if (full) {
             streamStore16(p.writeThrough, p.rgb + o, rgba[hf][0], rgba[hf][1], rgba[hf][2], rgba[hf][3]);
@@ -481,8 +674,9 @@ void bvhTraceKernel(const RasterParams p)
 
 size_t bvhLdsBytes(uint32_t passInst, bool textured)
 {
-    return (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + (size_t)(passInst / kWave) * 16 +
-           sizeof(WaveScratch) * kBvhWaves + (textured ? (size_t)kBvhWaves * kWave * kCold * 4 : 0);
+    const size_t cap = textured ? tabCap<true>() : tabCap<false>();
+    return 4096 * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 16 + (size_t)kBigCap * 64 +
+           (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + sizeof(WaveScratch) * kBvhWaves;
 }
 
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
@@ -498,13 +692,13 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     do {                                                                                       \
         static size_t allowed = 0;                                                             \
         if (lds > allowed) {                                                                   \
-            const hipError_t e = hipFuncSetAttribute((const void *)bvhTraceKernel<I, T>,       \
+            const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T>,        \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess)                                                               \
                 return e;                                                                      \
             allowed = lds;                                                                     \
         }                                                                                      \
-        bvhTraceKernel<I, T><<<grid, block, lds, stream>>>(p);                                 \
+        bvhTileKernel<I, T><<<grid, block, lds, stream>>>(p);                                  \
     } while (0)
     if (ids == 2) {
         if (tex) MRX_BVH(2, true); else MRX_BVH(2, false);

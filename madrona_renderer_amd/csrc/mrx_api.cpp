@@ -502,6 +502,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
         bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);
+    if (r.useBvh && maxWorldTris > kBvhMaxWorldTris)
+        return fail(MRX_E_UNSUPPORTED, "more than 2M triangles in one world");
     // per-view draw lists with a fixed stride (one load level in the kernel);
     // the BVH path walks the world's instances instead and needs none
     const uint32_t stride = maxWorldTris ? maxWorldTris : 1u;
@@ -523,11 +525,21 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     buildBlas(tris.data(), r.objFirst, r.objCount, blas);
     if (blas.leafTris.size() >= (1u << kBvhLeafStartBits))
         return fail(MRX_E_UNSUPPORTED, "too many triangles in BLAS leaves");
-    if (blas.objects.empty())
-        blas.objects.emplace_back();                  // the kernel reads entry 0 for idle lanes
+    // per instance: range, root and box of its (creation-time) object, so the
+    // per-step TLAS build has no load that depends on another
+    std::vector<ObjInfo> instInfo(instObj.size());
+    for (size_t i = 0; i < instObj.size(); ++i) {
+        ObjInfo info {};
+        info.root = -1;
+        if (instObj[i] >= 0 && (size_t)instObj[i] < blas.objects.size())
+            info = blas.objects[instObj[i]];
+        instInfo[i] = info;
+    }
+    if (instInfo.empty())
+        instInfo.emplace_back();                      // idle lanes read row 0
     MRX_HIP(r.bvhNodes.upload(blas.nodes));
     MRX_HIP(r.bvhLeafTris.upload(blas.leafTris));
-    MRX_HIP(r.objInfo.upload(blas.objects));
+    MRX_HIP(r.objInfo.upload(instInfo));
     MRX_HIP(r.worldInstStart.upload(worldInstStart));
     MRX_HIP(r.viewWorld.upload(viewWorld));
     MRX_HIP(r.instKBase.upload(instKBase));
@@ -664,14 +676,28 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         p.debugSlots = std::atoi(dbg);
     p.bvhNodes = r.bvhNodes.ptr;
     p.bvhLeafTris = r.bvhLeafTris.ptr;
-    p.objInfo = r.objInfo.ptr;
+    p.instInfo = r.objInfo.ptr;
     p.numObjects = (uint32_t)r.objFirst.size();
+    p.bvhUniInst = p.bvhUniCams = 0;
+    if (cfg.num_worlds > 0) {
+        bool uni = true;
+        for (uint32_t w = 1; uni && w < cfg.num_worlds; ++w)
+            uni = cfg.worlds[w].num_instances == cfg.worlds[0].num_instances &&
+                  cfg.worlds[w].num_cameras == cfg.worlds[0].num_cameras;
+        if (uni && cfg.worlds[0].num_instances > 0 && cfg.worlds[0].num_cameras > 0) {
+            p.bvhUniInst = cfg.worlds[0].num_instances;
+            p.bvhUniCams = cfg.worlds[0].num_cameras;
+        }
+    }
     p.worldInstStart = r.worldInstStart.ptr;
     p.viewWorld = r.viewWorld.ptr;
     p.instKBase = r.instKBase.ptr;
     // TLAS records of up to 128 instances stay in LDS at once (two workgroups
     // per CU); larger worlds take several passes
     p.bvhPassInst = std::min<uint32_t>(128u, std::max<uint32_t>(64u, (maxWorldInst + 63u) / 64u * 64u));
+    p.bvhSmallArea = 32;
+    if (const char *dbg = std::getenv("MRX_BVH_SMALL_AREA"))
+        p.bvhSmallArea = std::max(0, std::min(4096, std::atoi(dbg)));
     if (const char *dbg = std::getenv("MRX_BVH_PASS_INST"))
         p.bvhPassInst = std::min<uint32_t>(512u, std::max<uint32_t>(64u, (uint32_t)std::atoi(dbg) / 64u * 64u));
 

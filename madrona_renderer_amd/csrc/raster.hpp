@@ -123,12 +123,14 @@ struct RasterParams {
     //      built from, and each instance's first world-local triangle index
     const BvhNode *bvhNodes;
     const uint32_t *bvhLeafTris;
-    const ObjInfo *objInfo;          // [numObjects], at least one entry
+    const ObjInfo *instInfo;         // [I]: the ObjInfo of each instance's (creation-time) object
     uint32_t numObjects;
+    uint32_t bvhUniInst, bvhUniCams; // every world: this many instances / cameras (0: look the tables up)
     const uint32_t *worldInstStart;  // [worlds + 1]
     const uint32_t *viewWorld;       // [views]
     const uint32_t *instKBase;       // [I]
     uint32_t bvhPassInst;            // instances whose TLAS records fit LDS at once (multiple of 64)
+    int32_t bvhSmallArea;            // boxes of up to this many pixels are walked by their triangle's lane
 };
 
 // Kernel variants (mrx_config.kernel_variant).
@@ -146,6 +148,7 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
 // BVH path: per-step TLAS in LDS, wave-packet traversal of TLAS + BLAS,
 // exact S6 leaf test (bvh.hip).  p.bvhPassInst is filled in by the caller.
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream);
+constexpr uint32_t kBvhMaxWorldTris = 0x1FFFFEu;   // the depth buffer's key holds 21 bits of triangle index
 // dynamic LDS bytes one workgroup of the BVH kernel needs for `passInst` instance records
 size_t bvhLdsBytes(uint32_t passInst, bool textured);
 
