@@ -161,6 +161,15 @@ void bvhTileKernel(const RasterParams p)
     const uint32_t passInst = p.bvhPassInst;
     if (p.debugSkip & 16u)
         return;                                       // timing aid: bare launch
+    // diagnostic (MRX_DEBUG_STAMPS=1): waves 0-3 record 100 MHz stamps of their phases
+    unsigned long long *stamps = (p.debugStamps && wave < 4)
+        ? p.debugStamps + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
+#define MRX_STAMP(i)                                                           \
+    do {                                                                       \
+        if (stamps && lane == 0)                                               \
+            stamps[i] = __builtin_amdgcn_s_memrealtime();                      \
+    } while (0)
+    MRX_STAMP(0);
 
     // ---- LDS: depth buffer of the tile, shading records of the pass, control
     //      words, the TLAS of the pass, per-wave scratch
@@ -225,6 +234,8 @@ void bvhTileKernel(const RasterParams p)
     for (uint32_t passBase = i0; passBase < i1; passBase += passInst) {
         const uint32_t n = min(passInst, i1 - passBase);
         __syncthreads();                              // depth buffer initialised / previous TLAS consumed
+        if (threadIdx.x == 0)
+            ctrl[1] = 0u;                             // (every wave has read the last pass's count by now)
         // ---- phase I: the TLAS of this pass, in LDS.  Lane = (instance, corner of
         //      its object's box): transform (S2/S3) and S6b quantities per
         //      instance, one projected corner per lane, 8-lane reduction.
@@ -274,6 +285,7 @@ void bvhTileKernel(const RasterParams p)
             }
         }
         __syncthreads();
+        MRX_STAMP(1);
 
         // ---- phase II: geometry.  The waves split the work by instance: flat
         //      objects round-robin, the eight children of a BLAS root one per
@@ -281,6 +293,8 @@ void bvhTileKernel(const RasterParams p)
         uint32_t qCount = 0, sp = 0, chunk = 0, curInst = 0;
         const uint32_t numChunks = (n + kWave - 1) / kWave;
         uint64_t instMask = 0;
+        uint32_t vFirst = 0, vNum = 0;                // of the lane's instance of the current TLAS chunk
+        int32_t vRoot = -1;
         float sMV[3][3] = {}, sTv[3] = {};
         bool done = (p.debugSkip & 4u) != 0;          // timing aid: no traversal at all
         bool reported = false;
@@ -331,22 +345,24 @@ void bvhTileKernel(const RasterParams p)
                                 hm &= hm - 1;
                                 ws->stack[sp++] = (uint32_t)__builtin_amdgcn_readlane((int)cref, l);
                             }
+                            waveLdsSync();
                         }
                     } else if (instMask) {
-                        // next instance of this wave's share whose rectangle meets the tile
+                        // next instance of this wave's share whose rectangle meets the tile:
+                        // its range and root sit in the registers of the lane that tested it
                         const int b = __builtin_ctzll(instMask);
                         instMask &= instMask - 1;
                         curInst = (chunk - 1u) * kWave + (uint32_t)b;
-                        const float *rec = instRec + (size_t)curInst * kInstRecDw;
-                        const uint32_t first = rflu(__float_as_uint(rec[21]));
-                        const uint32_t num = rflu(__float_as_uint(rec[22]));
-                        const int32_t root = (int32_t)rflu(__float_as_uint(rec[23]));
+                        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)vFirst, b);
+                        const uint32_t num = (uint32_t)__builtin_amdgcn_readlane((int)vNum, b);
+                        const int32_t root = __builtin_amdgcn_readlane(vRoot, b);
                         if (root < 0) {
                             // flat object (<= kBvhFlatMax triangles): all of them
                             if ((uint32_t)lane < num)
                                 ws->queue[qCount + lane] = make_uint2(curInst, first + lane);
                             qCount += num;
                         } else {
+                            const float *rec = instRec + (size_t)curInst * kInstRecDw;
 #pragma unroll
                             for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -355,27 +371,33 @@ void bvhTileKernel(const RasterParams p)
                                 sTv[r] = rfl(rec[9 + r]);
                             }
                             ws->stack[sp++] = (uint32_t)root | kRootFlag;
+                            waveLdsSync();
                         }
                     } else if (chunk < numChunks) {
                         // next 64 instances of the TLAS: lane = instance
                         const uint32_t li = chunk * kWave + lane;
                         const float4 ir = instRect[li < n ? li : 0u];
+                        const float4 oi = *reinterpret_cast<const float4 *>(
+                            instRec + (size_t)(li < n ? li : 0u) * kInstRecDw + 20);
                         Rect r;
                         r.x0 = ir.x; r.x1 = ir.y; r.y0 = ir.z; r.y1 = ir.w;
+                        vFirst = __float_as_uint(oi.y);
+                        vNum = __float_as_uint(oi.z);
+                        vRoot = __float_as_int(oi.w);
                         const bool hitI = li < n && overlaps(r, TX0, TX1, TY0, TY1);
-                        const bool blas = __float_as_int(instRec[(size_t)(li < n ? li : 0u) * kInstRecDw + 23]) >= 0;
-                        instMask = __ballot(hitI && (blas || (lane & (kBvhWaves - 1)) == wave));
+                        instMask = __ballot(hitI && (vRoot >= 0 || (lane & (kBvhWaves - 1)) == wave));
                         ++chunk;
                     } else {
                         done = true;
                     }
-                    waveLdsSync();
                 }
                 if (qCount == 0)
                     break;
+                waveLdsSync();                        // the queue entries written above are read below
 
                 // -- a batch of up to 64 candidates: reserve shading records
                 const uint32_t nb = qCount < (uint32_t)kWave ? qCount : (uint32_t)kWave;
+                if (p.debugSkip & 128u) MRX_STAMP(2);
                 uint32_t slotBase = 0;
                 if (lane == 0)
                     slotBase = atomicAdd(&ctrl[0], nb);
@@ -418,6 +440,7 @@ void bvhTileKernel(const RasterParams p)
                         }
                     }
                 }
+                if (p.debugSkip & 128u) MRX_STAMP(3);
                 // pixel range of the triangle inside the tile: the conservative box
                 // of setup, less all but 1/32 of its one-pixel margin
                 const float kTrim = 0.96875f;
@@ -430,28 +453,41 @@ void bvhTileKernel(const RasterParams p)
                 const bool small = live && area <= smallArea;
                 const bool big = live && !small;
                 if (!(p.debugSkip & 2u)) {
-                    // -- small triangles: the lane walks the pixels of its triangle's box
+                    // -- small triangles: the lane walks its triangle's box, four pixels
+                    //    of a row per step (independent packed FMAs)
                     {
-                        int pxi = ix0, pyi = iy0;
-                        const int cnt = (small && !(p.debugSkip & 32u)) ? area : 0;
+                        const f32x2 A01 = { c.A0, c.A1 }, A2D = { c.A2, c.Dx };
+                        const f32x2 B01 = { c.B0, c.B1 }, B2D = { c.B2, c.Dy };
+                        const f32x2 C01 = { c.C0, c.C1 }, C2D = { c.C2, c.Dc };
+                        const int segs = (bw + 3) >> 2, xEnd = ix0 + bw;
+                        const int cnt = (small && !(p.debugSkip & 32u)) ? bh * segs : 0;
+                        int sx = ix0, sy = iy0;
                         for (int i = 0; __ballot(i < cnt) != 0; ++i) {
                             if (i < cnt) {
-                                const float px = (float)pxi, py = (float)pyi;
-                                const float e0 = __builtin_fmaf(c.A0, px, __builtin_fmaf(c.B0, py, c.C0));
-                                const float e1 = __builtin_fmaf(c.A1, px, __builtin_fmaf(c.B1, py, c.C1));
-                                const float e2 = __builtin_fmaf(c.A2, px, __builtin_fmaf(c.B2, py, c.C2));
-                                const float it = __builtin_fmaf(c.Dx, px, __builtin_fmaf(c.Dy, py, c.Dc));
-                                if (fminf(fminf(e0, e1), e2) >= 0.0f && it > invFar && it <= invNear)
-                                    atomicMax(&zbuf[(pyi - (int)tileY0) * 64 + (pxi - (int)tileX0)],
-                                              packHit(it, lowKey));
-                                ++pxi;
-                                if (pxi >= ix0 + bw) {
-                                    pxi = ix0;
-                                    ++pyi;
+                                const float py = (float)sy;
+                                const f32x2 yy = { py, py };
+                                const f32x2 r01 = fma2(B01, yy, C01);
+                                const f32x2 r2d = fma2(B2D, yy, C2D);
+                                unsigned long long *zrow = zbuf + (sy - (int)tileY0) * 64 + (sx - (int)tileX0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float px = (float)(sx + j);
+                                    const f32x2 pp = { px, px };
+                                    const f32x2 e01 = fma2(A01, pp, r01);
+                                    const f32x2 e2d = fma2(A2D, pp, r2d);
+                                    if (sx + j < xEnd && fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f &&
+                                        e2d.y > invFar && e2d.y <= invNear)
+                                        atomicMax(zrow + j, packHit(e2d.y, lowKey));
+                                }
+                                sx += 4;
+                                if (sx >= xEnd) {
+                                    sx = ix0;
+                                    ++sy;
                                 }
                             }
                         }
                     }
+                    if (p.debugSkip & 128u) MRX_STAMP(4);
                     // -- large triangles go on the tile's shared list: after the barrier all
                     //    eight waves rasterise them, each its own strip
                     uint64_t bigMask = __ballot(big && !(p.debugSkip & 64u));
@@ -552,7 +588,9 @@ void bvhTileKernel(const RasterParams p)
                 if (lane == 0)
                     atomicAdd(&ctrl[1], 1u);
             }
+            if (p.debugSkip & 128u) MRX_STAMP(5); else MRX_STAMP(2);
             __syncthreads();
+            if (!(p.debugSkip & 128u)) MRX_STAMP(3);
             // -- the round's large triangles: wave = strip, lane = entry for the box
             //    test, then four pixels of the lane per 32-pixel half
             {
@@ -596,6 +634,7 @@ void bvhTileKernel(const RasterParams p)
                     }
                 }
             }
+            if (!(p.debugSkip & 128u)) MRX_STAMP(4);
             __syncthreads();
             // -- resolve: every lane looks its eight pixels up; winners whose record
             //    is in the table of this round are shaded now (a later round reuses
@@ -623,14 +662,14 @@ void bvhTileKernel(const RasterParams p)
                                                         1.0f / __uint_as_float((uint32_t)(z >> 32)));
                     }
                 }
-            __syncthreads();
+            if (!(p.debugSkip & 128u)) MRX_STAMP(5);
             if (allDone)
-                break;
+                break;                                // (the next pass, if any, opens with a barrier)
+            __syncthreads();
         }
-        if (threadIdx.x == 0)
-            ctrl[1] = 0u;                             // (ordered by the barrier that opens the next pass)
     }
-    __syncthreads();
+    if (i0 >= i1)
+        __syncthreads();                              // an empty world: only the cleared depth buffer
 
     // ---- output: depth = 1/best (v_rcp_f32, <= 1 ulp), one 16-byte store per
     //      tensor and half
@@ -668,6 +707,8 @@ void bvhTileKernel(const RasterParams p)
                 }
         }
     }
+    MRX_STAMP(6);
+#undef MRX_STAMP
 }
 
 }  // namespace

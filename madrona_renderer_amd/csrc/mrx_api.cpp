@@ -494,11 +494,13 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     MRX_HIP(r.triMats.upload(triMats));
     MRX_HIP(r.textures.upload(texDescs));
     MRX_HIP(r.texels.upload(texels));
-    // Which kernel renders: worlds of more triangles than the group kernel has
-    // slots (256) go through the BVH path (bvh.hip), in both render modes.
-    // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH
-    // / the raster kernels.
-    uint32_t bvhMinTris = 257;
+    // Which kernel renders: the group kernel (raster.hip) wins on small worlds,
+    // the BVH path (bvh.hip) from about 190 triangles per world on (measured
+    // crossover at 1024 worlds x 64x64: 182 triangles equal, 254 triangles 14 %
+    // ahead, 482 triangles 2x -- profiles/r02_bvh_crossover.txt); it serves both
+    // render modes.  MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3
+    // force the BVH / the raster kernels.
+    uint32_t bvhMinTris = 192;
     if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
         bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);

@@ -35,6 +35,9 @@ def main():
     ]
     if len(sys.argv) > 1 and sys.argv[1] == "quick":
         cases = cases[:2]
+    if len(sys.argv) > 1 and sys.argv[1] == "crossover":
+        cases = [("1024 x 64^2, %d cubes (%d tris)" % (c, 12 * c + 2), meshes.cube_field(1024, c), 200)
+                 for c in (2, 5, 10, 15, 21, 30, 40)]
     for name, desc, steps in cases:
         row = []
         for variant in (2, 3):

@@ -1,0 +1,45 @@
+"""In-kernel timeline of the BVH kernel (MRX_DEBUG_STAMPS=1): per-phase
+durations of the workgroups, first and second generation."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MRX_DEBUG_STAMPS"] = "1"
+os.environ["MADRONA_MI355_KERNEL"] = "2"
+os.environ["MRX_PLACEMENT_TRIES"] = "1"
+import numpy as np
+import torch  # noqa
+import madrona_renderer_amd as pkg
+from madrona_renderer_amd import scenes
+from tests import meshes
+cubes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+worlds = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+desc = meshes.cube_field(worlds, cubes)
+r = scenes.make_renderer(desc)
+print('%.1f us/step' % (r.time_renders(100) / 100 * 1000))
+for _ in range(5):
+    r.step()
+r.sync()
+lib = pkg.load_capi()
+lib.mrx_debug_stamps.restype = ctypes.c_int64
+lib.mrx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+buf = np.zeros(worlds * 4 * 8, np.uint64)
+n = lib.mrx_debug_stamps(ctypes.c_void_p(r.native_handle()), buf.ctypes.data, buf.size)
+st = buf[:n].reshape(-1, 4, 8).astype(np.int64)
+t0 = st[:, :, 0].min()
+us = (st - t0) / 100.0
+names = ["entry", "TLAS built (barrier)", "produce done", "barrier 1", "large pass done", "resolve done (barrier 3)", "exit"]
+if os.environ.get("MRX_DEBUG_SKIP") == "128":
+    names = ["entry", "TLAS built (barrier)", "batch queued", "batch set up", "small walk done", "produce done", "exit"]
+entry = us[:, 0, 0]
+gen1 = entry < np.median(entry) - 1.0 if entry.max() - entry.min() > 4 else np.ones(len(entry), bool)
+for label, sel in (("first generation", gen1), ("second generation", ~gen1)):
+    if sel.sum() == 0:
+        continue
+    print("==", label, int(sel.sum()), "workgroups")
+    u = us[sel]
+    for i, nm in enumerate(names):
+        v = u[:, :, i].reshape(-1)
+        print(f"  {nm:26s} p10 {np.percentile(v, 10):6.2f}  p50 {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}")
+    d = np.diff(u[:, :, :7], axis=2)
+    print("  phase durations p50:", " ".join(f"{nm.split()[0]}:{np.median(d[:, :, i]):.2f}" for i, nm in enumerate(names[1:])))
+    print("  phase durations p90:", " ".join(f"{nm.split()[0]}:{np.percentile(d[:, :, i], 90):.2f}" for i, nm in enumerate(names[1:])))
+print("kernel span %.1f us" % us[:, :, 6].max())

@@ -313,8 +313,13 @@ def test_several_passes_of_256_triangles(native, cubes):
     d = _world(inst, [(CUBE, 0), (PLANE, 1)], cams,
                materials=[((0.9, 0.7, 0.5, 1.0), 0, 0.5, 0.5), ((0.3, 0.6, 0.3, 1.0), -1, 0.5, 0.5)],
                texture_paths=[os.path.join(scenes.DATA_DIR, "cube.png")], width=96, height=72)
-    _, got, _ = _parity(d)
+    _, got, _ = _parity(d)                                    # default dispatch: the BVH path
     assert got["tri_id"].max() >= min(256, 10 * cubes)        # later passes own pixels too
+    # the tiled raster kernels, forced (group kernel up to 256 triangles, chunked above)
+    r3 = make_product(d, visibility=True, variant=3)
+    got3 = fetch(r3)
+    for k in ("rgb", "depth", "tri_id"):
+        assert np.array_equal(got[k], got3[k])
 
 
 def test_edge_cases_empty_worlds_bad_ids_degenerate_triangles(native):
