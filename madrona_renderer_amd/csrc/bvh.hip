@@ -111,7 +111,7 @@ constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kBigRound = 8;                    // in-wave fallback: large triangles per round
 constexpr int kBigCap = 96;                     // shared list of large triangles per round of the tile
-constexpr int kSmallAreaDefault = 32;           // pixels of (trimmed) bounding box
+
 
 template <bool TEX> constexpr int tabCap() { return TEX ? 256 : 1024; }
 

@@ -100,11 +100,15 @@ size_t outPhase(const char *env, size_t dflt)
 }
 // Which kind of candidate the placement search starts with: tensors of 64 MiB
 // were reliably fast in one block, tensors of 256 MiB and 1 GiB one block each.
-bool firstKindIsOneBlock(size_t px) { return px * 4 < (128ull << 20); }
+bool firstKindIsOneBlock(size_t px)
+{
+    if (const char *dbg = std::getenv("MRX_OUT_KIND"))      // "one" | "split": diagnostic override
+        return dbg[0] == 'o';
+    return px * 4 < (128ull << 20);
+}
 
 hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint32_t> &rgb,
-                        DevBuf<float> &depth, DevBuf<int32_t> &ids,
-                        std::vector<DevBuf<uint8_t>> *spacers = nullptr, size_t gapBytes = 0)
+                        DevBuf<float> &depth, DevBuf<int32_t> &ids)
 {
     const size_t depthPhase = outPhase("MRX_OUT_SKEW_DEPTH_KB", 256u << 10);
     const size_t idsPhase = outPhase("MRX_OUT_SKEW_IDS_KB", 64u << 10);
@@ -115,10 +119,14 @@ hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint
         // candidate of the placement search: half-GiB outputs were only ever
         // fast this way, 128 MiB ones reliably only in one allocation.
         hipError_t e = rgb.alloc(px);
-        auto gap = [&]() {                            // the search also varies what lies between the tensors
+        size_t gapBytes = 0;
+        if (const char *dbg = std::getenv("MRX_OUT_GAP_MB"))    // diagnostic: a held allocation between the tensors
+            gapBytes = (size_t)std::atoll(dbg) << 20;
+        static std::vector<DevBuf<uint8_t>> heldGaps;            // (only ever filled by the diagnostic knob)
+        auto gap = [&]() {
             DevBuf<uint8_t> sp;
-            if (spacers && gapBytes && sp.alloc(gapBytes) == hipSuccess)
-                spacers->push_back(sp);
+            if (gapBytes && sp.alloc(gapBytes) == hipSuccess)
+                heldGaps.push_back(sp);
         };
         if (e == hipSuccess) {
             gap();
@@ -561,7 +569,18 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // image y (callers read it as [x][y]: scripts/test.py:160, dump.cpp:9-21)
     const uint32_t nfast = rt ? H : W, nslow = rt ? W : H;
     const size_t px = (size_t)nviews * nfast * nslow;
-    MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), firstKindIsOneBlock(px), r.rgb, r.depth, r.ids));
+    {
+        // diagnostic: a block allocated ahead of the outputs (MRX_OUT_PRE_MB), freed
+        // again right after them unless MRX_OUT_PRE_HOLD=1
+        DevBuf<uint8_t> pre;
+        if (const char *dbg = std::getenv("MRX_OUT_PRE_MB"))
+            if (pre.alloc((size_t)std::atoll(dbg) << 20) != hipSuccess)
+                (void)hipGetLastError();
+        MRX_HIP(allocOutputs(px, rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS), firstKindIsOneBlock(px), r.rgb, r.depth, r.ids));
+        const char *hold = std::getenv("MRX_OUT_PRE_HOLD");
+        if (!(hold && hold[0] == '1'))
+            pre.release();
+    }
     const bool wantIds = rt || (cfg.flags & MRX_FLAG_VISIBILITY_IDS);
 
     RasterParams &p = r.params;
@@ -741,35 +760,46 @@ int mrx_device_count(void)
     return n;
 }
 
-// Where the output tensors land in HBM matters: the same launch streams its
-// stores 7 % (128 MiB of output) to 20 % (0.5 - 3 GiB) faster into some
-// allocations than into others, steadily for the life of the allocation and
-// whatever the kernel does ("placement").  Nothing visible from
-// user space predicts which, so candidates are allocated one after another --
-// alternately all tensors in one allocation and one allocation per tensor,
-// with spacers of varying size between them --, each is timed with a few renders,
-// and the search stops as soon as one is clearly faster than the slowest seen
-// (small outputs: after four).  The fastest is kept, the rest freed.
+// Where LARGE output tensors land in HBM matters on some boxes: with tensors of
+// 256 MiB and more the same launch streams its stores ~20 % faster into some
+// allocations than into others, steadily for the life of the allocation
+// (profiles/r02_placement.txt).  Nothing visible from user space
+// predicts which -- not the layout, not the distance between the tensors, not
+// the address; some boxes offer no fast allocation at all -- so for such
+// outputs a few candidates are allocated one after another (alternately all
+// tensors in one block and one block per tensor), each timed with a few
+// renders, and the fastest kept.  Bounded: at most two candidates (the best so
+// far and the current one) plus one small spacer are alive at any time, at most
+// four are tried, and nothing is tried when two more copies of the outputs
+// would not fit a quarter of the free memory.  Outputs below 256 MiB (every
+// 64x64 batch up to 8192 views) are laid out deterministically in one block --
+// depth at phase 256 KiB of the 512 KiB period -- and need no search: all their
+// candidates measured the same.  MRX_PLACEMENT_TRIES=1 switches the search off.
 static int choosePlacement(mrx_renderer *r)
 {
     const size_t px = r->rgb.count;
     const bool wantIds = r->ids.ptr != nullptr;
     const size_t bytes = px * 4 * (wantIds ? 3 : 2);
-    int maxTries = bytes == 0 ? 1 : bytes <= (256ull << 20) ? 16 : bytes <= (8ull << 30) ? 12 : 1;
+    int maxTries = (bytes >= (256ull << 20) && bytes <= (16ull << 30)) ? 4 : 1;
     if (const char *dbg = std::getenv("MRX_PLACEMENT_TRIES"))
-        maxTries = std::max(1, std::min(32, std::atoi(dbg)));
+        maxTries = std::max(1, std::min(16, std::atoi(dbg)));
+    if (maxTries > 1) {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || 2 * bytes + (256ull << 20) > freeB / 4) {
+            (void)hipGetLastError();
+            maxTries = 1;
+        }
+    }
     if (maxTries <= 1)
         return MRX_OK;
     const bool trace = std::getenv("MRX_PLACEMENT_TRACE") != nullptr;
     struct Cand { DevBuf<uint32_t> rgb; DevBuf<float> depth; DevBuf<int32_t> ids; float us = 0.0f; };
-    std::vector<Cand> cand(1);
-    cand[0].rgb = r->rgb; cand[0].depth = r->depth; cand[0].ids = r->ids;   // what buildScene allocated
-    std::vector<DevBuf<uint8_t>> spacers;
     auto bind = [&](const Cand &c) {
         r->params.rgb = c.rgb.ptr;
         r->params.depth = c.depth.ptr;
         r->params.ids = wantIds ? c.ids.ptr : nullptr;
     };
+    auto freeCand = [](Cand &c) { c.rgb.release(); c.depth.release(); c.ids.release(); };
     auto launch = [&]() { return r->launch(); };
     auto timeBatch = [&](int n, float &ms) -> hipError_t {
         hipError_t e = hipEventRecord(r->ev0, r->stream);
@@ -780,9 +810,11 @@ static int choosePlacement(mrx_renderer *r)
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, r->ev0, r->ev1);
         return e;
     };
-    // a render takes ~10 us to ~1 ms: batches of ~0.5 ms, ~40 ms of warm-up (clocks)
+    Cand best;
+    best.rgb = r->rgb; best.depth = r->depth; best.ids = r->ids;   // what buildScene allocated
+    // a render takes ~0.1 - 1 ms here: batches of ~0.5 ms, ~40 ms of warm-up (clocks)
     hipError_t st = hipSuccess;                   // first error; the cleanup below always runs
-    bind(cand[0]);
+    bind(best);
     float one = 0.0f;
     st = launch();
     if (st == hipSuccess) st = timeBatch(1, one);
@@ -793,70 +825,57 @@ static int choosePlacement(mrx_renderer *r)
     auto measure = [&](Cand &c) -> hipError_t {
         bind(c);
         hipError_t e = launch();
-        float best = 1e30f, ms = 0.0f;
+        float bestMs = 1e30f, ms = 0.0f;
         for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {
             e = timeBatch(batch, ms);
-            best = std::min(best, ms);
+            bestMs = std::min(bestMs, ms);
         }
-        c.us = best / (float)batch * 1000.0f;
+        c.us = bestMs / (float)batch * 1000.0f;
         return e;
     };
-    if (st == hipSuccess) st = measure(cand[0]);
-    float tmin = cand[0].us, tmax = cand[0].us;
-    int best = 0;
+    if (st == hipSuccess) st = measure(best);
+    float tmax = best.us;
+    std::string log;
+    char buf[64];
+    std::snprintf(buf, sizeof buf, " %.2f", best.us);
+    log += buf;
     for (int k = 1; k < maxTries && st == hipSuccess; ++k) {
-        // spacers of 2 ... 128 MiB step the candidates through the address space
+        // a spacer of 2 ... 128 MiB steps the next candidate on in the address space;
+        // the best candidate so far stays allocated, so the new one cannot reuse its block
         DevBuf<uint8_t> sp;
-        // (large outputs: also by multiples of half their size, out of the holes
-        // earlier renderers of the process left behind)
-        const size_t hop = bytes > (256ull << 20) ? (size_t)(k % 4) * (bytes / 2) : 0;
-        if (sp.alloc(hop + ((size_t)(2 * ((k * 37) % 64 + 1)) << 20)) == hipSuccess)
-            spacers.push_back(sp);
-        else
+        if (sp.alloc((size_t)(2 * ((k * 37) % 64 + 1)) << 20) != hipSuccess)
             (void)hipGetLastError();
         Cand c;
-        static const size_t kGapsMiB[6] = { 0, 2, 34, 66, 18, 98 };
-        if (allocOutputs(px, wantIds, ((k & 1) == 0) == firstKindIsOneBlock(px), c.rgb, c.depth, c.ids,
-                         &spacers, kGapsMiB[(k / 2) % 6] << 20) != hipSuccess) {
+        const hipError_t ae = allocOutputs(px, wantIds, ((k & 1) == 0) == firstKindIsOneBlock(px),
+                                           c.rgb, c.depth, c.ids);
+        sp.release();
+        if (ae != hipSuccess) {
             (void)hipGetLastError();                  // out of memory: make do with what there is
             break;
         }
-        cand.push_back(c);
-        st = measure(cand.back());
-        if (st != hipSuccess)
+        st = measure(c);
+        if (st != hipSuccess) {
+            freeCand(c);
             break;
-        const float us = cand.back().us;
-        if (us < tmin) {
-            tmin = us;
-            best = k;
         }
-        tmax = std::max(tmax, us);
-        // the two modes lie 7 % (small outputs) to 20 % apart; candidates of one
-        // mode scatter by +-0.5 % (small) to +-4 % (large)
-        if (tmin <= (bytes <= (256ull << 20) ? 0.965f : 0.88f) * tmax)
+        std::snprintf(buf, sizeof buf, " %.2f", c.us);
+        log += buf;
+        tmax = std::max(tmax, c.us);
+        if (c.us < best.us) {
+            freeCand(best);
+            best = c;
+        } else {
+            freeCand(c);
+        }
+        // the two modes lie ~20 % apart, candidates of one mode scatter by +-4 %
+        if (best.us <= 0.88f * tmax)
             break;                                    // a fast placement
-        if (bytes <= (256ull << 20) && k >= 3)
-            break;                                    // small outputs: one block is reliably fast
     }
-    if (trace) {
-        std::fprintf(stderr, "mrx: output placement, us/render:");
-        for (size_t k = 0; k < cand.size(); ++k)
-            std::fprintf(stderr, " %.2f%s", cand[k].us, (int)k == best ? "*" : "");
-        std::fprintf(stderr, "\n");
-        if (std::getenv("MRX_PLACEMENT_ADDR"))
-            for (size_t k = 0; k < cand.size(); ++k)
-                std::fprintf(stderr, "mrx:   %.2f rgb %p depth %p\n", cand[k].us, (void *)cand[k].rgb.ptr,
-                             (void *)cand[k].depth.ptr);
-    }
-    for (auto &sp : spacers)
-        sp.release();
-    for (size_t k = 0; k < cand.size(); ++k) {
-        if ((int)k == best)
-            continue;
-        cand[k].rgb.release(); cand[k].depth.release(); cand[k].ids.release();
-    }
-    r->rgb = cand[best].rgb; r->depth = cand[best].depth; r->ids = cand[best].ids;
-    bind(cand[best]);
+    if (trace)
+        std::fprintf(stderr, "mrx: output placement, us/render:%s -> %.2f (rgb %p depth %p)\n", log.c_str(),
+                     best.us, (void *)best.rgb.ptr, (void *)best.depth.ptr);
+    r->rgb = best.rgb; r->depth = best.depth; r->ids = best.ids;
+    bind(best);
     if (st != hipSuccess)
         return fail(MRX_E_HIP, std::string("output placement: ") + hipGetErrorString(st));
     return MRX_OK;
