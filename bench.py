@@ -10,6 +10,14 @@ A "step" is one render of every view of the rank's worlds into the contiguous
 [views,H,W,4] RGBA8 + [views,H,W,1] f32 depth tensors; worlds shard across
 ranks with no data-path collective (weak scaling: --worlds per GPU).  Rank 0
 prints ONE JSON line.
+
+Other workloads of BASELINE.json are selected with flags (the default is the
+north-star configuration, 4096 worlds x 64x64 cube+plane):
+  --worlds 1024                                    configs[1]
+  --worlds 4096 --width 128 --height 128 --wall    configs[2]
+  --worlds 2048 [--first-world 14336]              one rank's shard of configs[3]
+  --worlds 4096 --width 256 --height 256 --textured --mode Raytracer [--variant 2]   configs[4]
+  --cubes 40 --worlds 1024                         many-instance worlds (BVH path)
 """
 import argparse
 import json
@@ -21,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+SETTLE_S = 0.25          # untimed renders before the warm-up (clocks leave idle only under load)
 
 
 def parse():
@@ -32,6 +41,14 @@ def parse():
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--wall", action="store_true", help="add wall_render.obj (config C3)")
+    ap.add_argument("--textured", action="store_true", help="cube textured with cube.png (config C5)")
+    ap.add_argument("--mode", default="Rasterizer", choices=["Rasterizer", "Raytracer"])
+    ap.add_argument("--cubes", type=int, default=0,
+                    help="many-instance worlds: this many cubes + plane per world (tests/meshes.py)")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="mrx_config.kernel_variant: 0 default dispatch, 2 BVH path, 3 raster kernels")
+    ap.add_argument("--first-world", type=int, default=None,
+                    help="global id of this rank's first world (default: rank * worlds)")
     ap.add_argument("--gather", action="store_true",
                     help="also time an RCCL all-gather of the output slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -61,15 +78,51 @@ def timed_steps(r, steps, barrier):
     return t1 - t0, r.elapsed_ms()
 
 
+def workload_tag(a, n_gpus):
+    """Key of profiles/pmc_latest.json: the full configuration, so that a
+    counter figure is only ever attached to the run it was measured on."""
+    tag = "%dx%dx%d" % (a.worlds, a.width, a.height)
+    if a.wall:
+        tag += "+wall"
+    if a.textured:
+        tag += "+tex"
+    if a.mode != "Rasterizer":
+        tag += "+rt"
+    if a.cubes:
+        tag += "+cubes%d" % a.cubes
+    if a.variant:
+        tag += "+variant%d" % a.variant
+    if n_gpus != 1:
+        tag += "+gpus%d" % n_gpus
+    return tag
+
+
 def pmc_traffic(tag):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this
-    same command (profiles/), or None."""
+    """(HBM bytes per launch, where the figure comes from) from the committed
+    rocprofv3 --pmc summaries of this same command (profiles/pmc_latest.json),
+    or (None, None): the counters are not collected by this run."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
-            return json.load(f).get(tag)
+            table = json.load(f)
     except Exception:
-        return None
+        return None, None
+    ent = table.get(tag)
+    if ent is None:
+        return None, None
+    if isinstance(ent, dict):
+        return ent.get("bytes"), "static: profiles/pmc_latest.json <- %s" % ent.get("source", "?")
+    return ent, "static: profiles/pmc_latest.json"
+
+
+def make_scene(a, first_world, worlds=None, scenes=None):
+    worlds = a.worlds if worlds is None else worlds
+    if a.cubes:
+        from tests import meshes
+        return meshes.cube_field(worlds, a.cubes, width=a.width, height=a.height, mode=a.mode,
+                                 textured=a.textured, first_world=first_world)
+    return scenes.synthetic_scene(worlds, width=a.width, height=a.height, with_wall=a.wall,
+                                  textured=a.textured, render_mode=a.mode, first_world=first_world)
 
 
 def main():
@@ -86,7 +139,9 @@ def main():
     rehearsal = os.environ.get("MRX_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-    if world > 1:
+    # under torch.distributed.run (RANK is set) the process group is RCCL even
+    # for one rank, so that init, device binding and the collectives run for real
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         if rehearsal:
@@ -103,16 +158,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    desc = scenes.synthetic_scene(a.worlds, width=a.width, height=a.height,
-                                  with_wall=a.wall, first_world=rank * a.worlds)
+    if a.variant:
+        os.environ["MADRONA_MI355_KERNEL"] = str(a.variant)
+    first = rank * a.worlds if a.first_world is None else a.first_world
+    desc = make_scene(a, first, scenes=scenes)
     r = scenes.make_renderer(desc, gpu_id=local)
     views = desc.num_views
     # The card leaves its idle power state only after some tens of milliseconds
     # of load (a 25 us step runs ~10 % slower until then), so the W warm-up
-    # steps are preceded by a quarter second of untimed renders.
+    # steps are preceded by a quarter second of untimed renders (`settle_s`).
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.25:
-        r.time_renders(1000)
+    settle_renders = 0
+    while time.perf_counter() - t_settle < SETTLE_S:
+        r.time_renders(100)
+        settle_renders += 100
     for _ in range(a.warmup):
         r.step()
     wall, dev_ms = timed_steps(r, a.steps, barrier)
@@ -126,6 +185,10 @@ def main():
     bytes_per_launch = int(r.bytes_per_step())
     kern_us = dev_ms * 1000.0 / a.steps
     achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
+    achieved_wall = bytes_per_launch / (wall / a.steps) / 1e9
+    traffic, traffic_source = pmc_traffic(workload_tag(a, n_gpus))
+    scene_txt = ("%d cubes + plane" % a.cubes) if a.cubes else \
+        "cube+plane%s%s" % ("+wall" if a.wall else "", ", textured" if a.textured else "")
     out = {
         "metric": "rendered views/sec (whole node), N worlds x %dx%d RGB+depth" % (a.width, a.height),
         "value": value,
@@ -133,6 +196,8 @@ def main():
         "n_gpus": n_gpus,
         "steps": a.steps,
         "warmup": a.warmup,
+        "settle_s": SETTLE_S,
+        "settle_renders": settle_renders,
         "ms_per_step": wall * 1000.0 / a.steps,
         "higher_is_better": True,
         "scaling": "weak",
@@ -140,18 +205,23 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "%d worlds/GPU x %dx%d RGBA8 + f32 depth, cube+plane%s, "
-                        "Rasterizer mode, one camera/world" % (
-                            a.worlds, a.width, a.height, "+wall" if a.wall else ""),
+            "workload": "%d worlds/GPU x %dx%d RGBA8 + f32 depth, %s, %s mode, one camera/world" % (
+                a.worlds, a.width, a.height, scene_txt, a.mode),
             "worlds_per_gpu": a.worlds, "views_total": total_views,
             "width": a.width, "height": a.height,
+            "kernel_variant": a.variant,
             "parallelism": "worlds sharded x%d, no collective" % n_gpus,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic("%dx%dx%d" % (a.worlds, a.width, a.height)),
-            "kernel": "mrx raster (one launch per step)",
+            # frac_kernel: from the kernel's average launch duration (HIP events on the
+            # launch stream around the K launches); frac_wall: from the host clock
+            # around the same K steps (what `value` is computed from)
+            "frac_kernel": achieved / HBM_PEAK_GBPS,
+            "frac_wall": achieved_wall / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "mrx %s (one launch per step)" % r.render_path(),
             "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch,
         },
     }
@@ -172,13 +242,16 @@ def main():
             dist.all_gather_into_tensor(g_dep, dep)
         torch.cuda.synchronize(); barrier()
         gw = time.perf_counter() - t0
+        # the slab of this rank inside the gathered tensor is what it rendered
+        same = bool(torch.equal(g_rgb[rank], rgb)) and bool(torch.equal(g_dep[rank], dep))
         out["with_gather"] = {"value": total_views * a.steps / gw, "unit": "views/s",
                               "ms_per_step": gw * 1000.0 / a.steps,
-                              "collective": "RCCL all_gather_into_tensor rgb+depth"}
+                              "collective": "RCCL all_gather_into_tensor rgb+depth",
+                              "backend": dist.get_backend(), "own_slab_intact": same}
 
     if rank == 0 and n_gpus == 1 and not a.no_extra and a.worlds != 1024:
         # BASELINE.json configs[1]: 1024 worlds, same scene, reported beside it
-        d2 = scenes.synthetic_scene(1024, width=a.width, height=a.height, with_wall=a.wall)
+        d2 = make_scene(a, 0, worlds=1024, scenes=scenes)
         r2 = scenes.make_renderer(d2, gpu_id=local)
         for _ in range(a.warmup):
             r2.step()
@@ -194,7 +267,7 @@ def main():
         # this repo's scalar oracle on the host cores of this box.
         from oracle import oracle
         nv = min(a.cpu_views, views)
-        dcpu = scenes.synthetic_scene(nv, width=a.width, height=a.height, with_wall=a.wall)
+        dcpu = make_scene(a, 0, worlds=nv, scenes=scenes)
         fs = oracle.FlatScene(dcpu)
         # a 1-GPU box owns a 16-core share of its host; stay inside it
         nthr = max(1, min(len(os.sched_getaffinity(0)), a.cpu_threads))

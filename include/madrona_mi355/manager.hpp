@@ -95,6 +95,7 @@ public:
     uint64_t bytesPerStep() const;                  // algorithmic HBM bytes / render
     void *nativeHandle() const;                     // mrx_renderer *
     void setStream(void *hipStream);                // launch on this stream from now on
+    const char *renderPath() const;                 // "raster" (tiled raster kernels) or "bvh"
 
     uint32_t numAgents;
 

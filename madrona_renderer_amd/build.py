@@ -123,7 +123,7 @@ def build_headless(force=False, verbose=False):
                "-DMRX_DATA_DIR=\"%s\"" % os.path.join(ROOT, "data"),
                os.path.join(CSRC, "headless.cpp"), os.path.join(CSRC, "manager.cpp"),
                os.path.join(CSRC, "assets.cpp"),
-               "-L" + HERE, "-lmrx_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-o", out]
+               "-L" + HERE, "-lmrx_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", out]
         _run(cmd, verbose)
     return out
 

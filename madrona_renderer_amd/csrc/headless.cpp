@@ -4,7 +4,13 @@
 //
 //   renderer_headless NUM_WORLDS NUM_STEPS rt|rast BATCH_WIDTH BATCH_HEIGHT
 //                     [--dump-last-frame file_name_without_extension]
-//                     [--scene synthetic|demo] [--depth]
+//                     [--scene synthetic|demo] [--depth] [--gpus N]
+//
+// --gpus N (no counterpart upstream: the reference has a single gpuID,
+// mgr.hpp:50) shards the worlds over N devices of the node: one host thread
+// and one Manager per device, contiguous world ranges whose sizes differ by at
+// most one, no exchange between the devices.  A line per device and the two
+// reference lines for the whole node are printed.
 //
 // It steps the renderer NUM_STEPS times, prints the reference's two lines
 // (`FPS`, `Average total step time`) and optionally writes the last frame of
@@ -12,12 +18,14 @@
 // a scene (headless.cpp:48-55 passes no rcfg); here the scene is either the
 // synthetic cube+plane worlds of the benchmark or the reference's demo scene
 // (viewer.cpp:74-164 / scripts/test.py:11-130).
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/madrona_mi355/manager.hpp"
@@ -40,6 +48,7 @@ struct Args {
     uint32_t numWorlds = 0, numSteps = 0, width = 64, height = 64;
     Mode mode = Mode::Rasterizer;
     bool dump = false, dumpDepth = false, demo = false;
+    uint32_t gpus = 1;
     std::string outName;
 };
 
@@ -47,7 +56,7 @@ struct Args {
 {
     std::fprintf(stderr,
                  "%s [NUM_WORLDS] [NUM_STEPS] [rt|rast] [BATCH_WIDTH] [BATCH_HEIGHT] "
-                 "[--dump-last-frame file_name_without_extension] [--scene synthetic|demo] [--depth]\n",
+                 "[--dump-last-frame file_name_without_extension] [--scene synthetic|demo] [--depth] [--gpus N]\n",
                  argv0);
     std::exit(EXIT_FAILURE);
 }
@@ -72,11 +81,13 @@ Args parse(int argc, char **argv)
             a.demo = !std::strcmp(argv[++i], "demo");
         } else if (!std::strcmp(argv[i], "--depth")) {
             a.dumpDepth = true;
+        } else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) {
+            a.gpus = (uint32_t)std::atoi(argv[++i]);
         } else {
             usage(argv[0]);
         }
     }
-    if (a.numWorlds == 0 || a.width == 0 || a.height == 0)
+    if (a.numWorlds == 0 || a.width == 0 || a.height == 0 || a.gpus == 0 || a.gpus > a.numWorlds)
         usage(argv[0]);
     return a;
 }
@@ -141,7 +152,9 @@ struct Scene {
     std::vector<int32_t> meshMats;
 };
 
-void buildSynthetic(Scene &s, uint32_t n, const std::string &dataDir)
+// worlds [first, first + n) of the synthetic job: world ids are global, so a
+// shard holds exactly the rows it would own of the whole job's scene
+void buildSynthetic(Scene &s, uint32_t first, uint32_t n, const std::string &dataDir)
 {
     s.paths = { dataDir + "/cube.obj", dataDir + "/plane.obj" };
     s.matAssign = { 0, 0 };
@@ -152,7 +165,7 @@ void buildSynthetic(Scene &s, uint32_t n, const std::string &dataDir)
     for (uint32_t w = 0; w < n; ++w) {
         double u[12];
         for (int j = 0; j < 12; ++j)
-            u[j] = uniform((uint64_t)w * 16 + j);
+            u[j] = uniform((uint64_t)(first + w) * 16 + j);
         const double sc = 1.0 + 2.0 * u[2], th = 2.0 * pi * u[3];
         s.instances.push_back({ { 0.f, 0.f, 0.f }, { 1.f, 0.f, 0.f, 0.f }, { 1.f, 1.f, 1.f }, 1 });
         s.instances.push_back({ { (float)(-4 + 8 * u[0]), (float)(-4 + 8 * u[1]), (float)(0.5 * sc) },
@@ -229,23 +242,37 @@ bool dumpTiled(const std::string &name, Manager &mgr, uint32_t numImages, uint32
     return true;
 }
 
-}  // namespace
-
-int main(int argc, char **argv)
+// [lo, hi) of the worlds device `rank` of `n` renders: contiguous, sizes differ by <= 1
+// (the same split as madrona_renderer_amd/scenes.py shard_range)
+void shardRange(uint32_t worlds, uint32_t rank, uint32_t n, uint32_t &lo, uint32_t &hi)
 {
-    const Args args = parse(argc, argv);
-    const char *dd = std::getenv("MADRONA_MI355_DATA");
-    const std::string dataDir = dd ? dd : MRX_DATA_DIR;
+    const uint32_t base = worlds / n, rem = worlds % n;
+    lo = rank * base + (rank < rem ? rank : rem);
+    hi = lo + base + (rank < rem ? 1u : 0u);
+}
 
+struct Shard {
+    uint32_t lo = 0, hi = 0;
+    int gpu = 0;
+    double seconds = 0.0;
+    bool ok = false;
+};
+
+// One device's share of the job: its own scene rows, its own Manager, NUM_STEPS
+// steps between two rendezvous with the other devices' threads.
+void runShard(const Args &args, const std::string &dataDir, Shard &sh, std::atomic<uint32_t> &ready,
+              uint32_t parties, const std::string &dumpName)
+{
+    const uint32_t n = sh.hi - sh.lo;
     Scene s;
-    if (args.demo) buildDemo(s, args.numWorlds, dataDir);
-    else buildSynthetic(s, args.numWorlds, dataDir);
+    if (args.demo) buildDemo(s, n, dataDir);
+    else buildSynthetic(s, sh.lo, n, dataDir);
     for (auto &p : s.paths) s.pathPtrs.push_back(p.c_str());
     for (auto &p : s.texPaths) s.texPtrs.push_back(p.c_str());
 
     Manager::Config cfg {};
-    cfg.gpuID = 0;
-    cfg.numWorlds = args.numWorlds;
+    cfg.gpuID = sh.gpu;
+    cfg.numWorlds = n;
     cfg.renderMode = args.mode == Mode::Raycaster ? Manager::RenderMode::Raytracer
                                                   : Manager::RenderMode::Rasterizer;
     cfg.batchRenderViewWidth = args.width;
@@ -269,26 +296,73 @@ int main(int argc, char **argv)
     rc.numCameras = (uint32_t)s.cameras.size();
     rc.worlds = s.worlds.data();
 
-    Manager mgr(cfg);
+    Manager mgr(cfg);              // aborts (FATAL) on failure, like the reference
     mgr.sync();
+    // every device starts stepping together
+    ready.fetch_add(1);
+    while (ready.load() < parties)
+        std::this_thread::yield();
 
     const auto start = std::chrono::system_clock::now();
     for (uint32_t i = 0; i < args.numSteps; ++i)
         mgr.step();
     mgr.sync();
     const auto end = std::chrono::system_clock::now();
-    const std::chrono::duration<double> elapsed = end - start;
+    sh.seconds = std::chrono::duration<double>(end - start).count();
 
+    sh.ok = true;
     if (args.dump) {
         const bool rt = args.mode == Mode::Raycaster;
         const uint32_t resY = rt ? args.width : args.height;
-        if (!dumpTiled(args.outName, mgr, args.numWorlds, args.width, resY, args.dumpDepth, rt))
-            return EXIT_FAILURE;
+        sh.ok = dumpTiled(dumpName, mgr, n, args.width, resY, args.dumpDepth, rt);
+    }
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    const Args args = parse(argc, argv);
+    const char *dd = std::getenv("MADRONA_MI355_DATA");
+    const std::string dataDir = dd ? dd : MRX_DATA_DIR;
+    // MRX_HEADLESS_REHEARSAL=1: every shard on device 0 -- walks the N-device
+    // control flow on a one-GPU box (the numbers then mean nothing)
+    const char *reh = std::getenv("MRX_HEADLESS_REHEARSAL");
+    const bool rehearsal = reh && reh[0] == '1';
+    if (!rehearsal && (int)args.gpus > mrx_device_count()) {
+        std::fprintf(stderr, "--gpus %u but %d HIP device(s) visible\n", args.gpus, mrx_device_count());
+        return EXIT_FAILURE;
     }
 
-    const double fps = (double)args.numSteps * (double)args.numWorlds / elapsed.count();
+    std::vector<Shard> shards(args.gpus);
+    std::atomic<uint32_t> ready { 0 };
+    std::vector<std::thread> threads;
+    for (uint32_t g = 0; g < args.gpus; ++g) {
+        shardRange(args.numWorlds, g, args.gpus, shards[g].lo, shards[g].hi);
+        shards[g].gpu = rehearsal ? 0 : (int)g;
+        const std::string name = args.gpus == 1 ? args.outName : args.outName + ".gpu" + std::to_string(g);
+        threads.emplace_back(runShard, std::cref(args), std::cref(dataDir), std::ref(shards[g]),
+                             std::ref(ready), args.gpus, name);
+    }
+    for (auto &t : threads)
+        t.join();
+
+    double slowest = 0.0;
+    bool ok = true;
+    for (uint32_t g = 0; g < args.gpus; ++g) {
+        const Shard &sh = shards[g];
+        ok = ok && sh.ok;
+        slowest = sh.seconds > slowest ? sh.seconds : slowest;
+        if (args.gpus > 1)
+            std::printf("GPU %d: worlds [%u, %u) FPS %f\n", sh.gpu, sh.lo, sh.hi,
+                        (double)args.numSteps * (double)(sh.hi - sh.lo) / sh.seconds);
+    }
+    if (!ok)
+        return EXIT_FAILURE;
+    // whole node: every world of the job over the slowest device's time
+    const double fps = (double)args.numSteps * (double)args.numWorlds / slowest;
     std::printf("FPS %f\n", fps);
     std::printf("Average total step time: %f ms\n",
-                1000.0 * elapsed.count() / (double)(args.numSteps ? args.numSteps : 1));
+                1000.0 * slowest / (double)(args.numSteps ? args.numSteps : 1));
     return 0;
 }

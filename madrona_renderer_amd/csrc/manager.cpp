@@ -185,6 +185,14 @@ uint64_t Manager::bytesPerStep() const
 
 void *Manager::nativeHandle() const { return impl_->r; }
 
+const char *Manager::renderPath() const
+{
+    mrx_info_t info {};
+    if (mrx_info(impl_->r, &info) != MRX_OK)
+        detail::fatal(mrx_last_error());
+    return info.render_path == 1 ? "bvh" : "raster";
+}
+
 void Manager::setStream(void *hipStream)
 {
     if (mrx_set_stream(impl_->r, hipStream) != MRX_OK)

@@ -319,6 +319,7 @@ PYBIND11_MODULE(madrona_renderer, m)
         .def("mark", &Manager::mark, py::arg("which"))
         .def("elapsed_ms", &Manager::elapsedMs)
         .def("bytes_per_step", &Manager::bytesPerStep)
+        .def("render_path", [](Manager &self) { return std::string(self.renderPath()); })
         .def("native_handle", [](Manager &self) { return (uint64_t)self.nativeHandle(); })
         // e.g. r.set_stream(torch.cuda.current_stream().cuda_stream): pose writes and
         // step() are then ordered on that stream without a host synchronisation
