@@ -89,6 +89,9 @@ public:
 
     // Additions with no counterpart in the reference (measurement / tests).
     madrona::py::Tensor visibilityTensor() const;   // needs MADRONA_MI355_VISIBILITY=1
+    // i32 [instances], mutable: negative hides the instance from the next step on
+    // (the ObjectID column, src/sim.cpp:152-156; src/sim.inl:5-16)
+    madrona::py::Tensor instanceObjectTensor() const;
     float timeRenders(int steps);                   // device ms for `steps` renders
     void mark(int which);                           // HIP event 0/1 on the stream
     float elapsedMs();                              // event1 - event0, waits for 1

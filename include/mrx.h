@@ -135,7 +135,14 @@ enum {
     MRX_BUF_CAMERA_ROTATION = 6,   /* f32 [cameras,4]                                */
     MRX_BUF_VISIBILITY = 7,     /* i32 [views,H,W], needs MRX_FLAG_VISIBILITY_IDS    */
     MRX_BUF_INSTANCE_SCALE = 8, /* f32 [instances,3]                                 */
-    MRX_NUM_BUFFERS = 9
+    /* i32 [instances], mutable: the ObjectID column of the renderables
+     * (/root/reference/src/sim.cpp:152-156).  A negative value hides the instance
+     * from the next step on (cleanupRenderableEntity, src/sim.inl:10-16), writing
+     * the id back shows it again (makeEntityRenderable, src/sim.inl:5-8).  Only
+     * the sign is interpreted: the geometry an instance draws is bound when the
+     * renderer is created, and triangle slots / visibility ids stay where they are. */
+    MRX_BUF_INSTANCE_OBJECT = 9,
+    MRX_NUM_BUFFERS = 10
 };
 
 enum { MRX_DTYPE_U8 = 0, MRX_DTYPE_I32 = 1, MRX_DTYPE_F32 = 2 };
@@ -209,6 +216,10 @@ int mrx_copy_triangles(mrx_renderer *r, float *tri_pos /*[T][9]*/,
 /* -- host-only asset readers (no device needed); free results with mrx_free */
 int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv,
                  uint32_t *num_tris);
+/*    The objects of an OBJ file (one per `o` / `g` block with faces,
+ *    /root/reference/src/mgr.cpp:294-307): writes up to `capacity` first-triangle
+ *    indices and returns the object count, or a negative MRX_E_*. */
+int mrx_obj_objects(const char *path, uint32_t *first_tri, uint32_t capacity);
 int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width,
                    uint32_t *height);
 /*    What the OBJ reader makes of a file's material statements, as JSON text:

@@ -82,6 +82,7 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
     out.triMtl.clear();
     out.mtlNames.clear();
     out.mtlLibs.clear();
+    out.objStart.assign(1, 0u);
     int32_t curMtl = -1;
 
     const char *p = (const char *)file.data();
@@ -153,6 +154,10 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
                 }
                 out.triMtl.push_back(curMtl);
             }
+        } else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t' || p[1] == '\r' || p[1] == '\n')) {
+            // a new object opens here unless the current one has no face yet
+            if (out.numTris() > out.objStart.back())
+                out.objStart.push_back(out.numTris());
         } else if (!std::strncmp(p, "usemtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
             const std::string name = restOfLine(p + 6, eol);
             curMtl = -1;

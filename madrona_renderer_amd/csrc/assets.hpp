@@ -10,10 +10,15 @@
 
 namespace mrx {
 
-// Object-space triangle soup of one object (one per OBJ file / raw mesh).
+// Object-space triangle soup of one OBJ file.  A file holds one object per
+// `o` / `g` block that has faces (faces ahead of the first statement form an
+// object of their own), the way the reference's importer hands back
+// ImportedAssets::objects (/root/reference/src/mgr.cpp:294-307); objStart lists
+// the first triangle of each.
 struct TriSoup {
     std::vector<float> pos;  // [T][3 verts][xyz]
     std::vector<float> uv;   // [T][3 verts][uv]
+    std::vector<uint32_t> objStart;   // first triangle of each object, ascending; at least one entry
     // `usemtl` of each triangle as an index into mtlNames, -1 = none
     std::vector<int32_t> triMtl;
     std::vector<std::string> mtlNames;

@@ -132,6 +132,8 @@ Tensor Manager::depthTensor() const { return impl_->wrap(MRX_BUF_DEPTH); }
 Tensor Manager::segmaskTensor() const { return impl_->wrap(MRX_BUF_SEGMASK); }
 Tensor Manager::visibilityTensor() const { return impl_->wrap(MRX_BUF_VISIBILITY); }
 
+Tensor Manager::instanceObjectTensor() const { return impl_->wrap(MRX_BUF_INSTANCE_OBJECT); }
+
 Tensor Manager::instancePositionTensor() const
 {
     return impl_->wrap(MRX_BUF_INSTANCE_POSITION);

@@ -339,7 +339,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         int32_t mat = -1;
         if (cfg.mat_assignments && a < cfg.num_mat_assignments)
             mat = cfg.mat_assignments[a];
-        appendObject(soup.pos.data(), soup.uv.data(), soup.numTris(), mat);
+        // one object per `o` / `g` block of the file (mgr.cpp:294-307: objects, plural)
+        for (size_t o = 0; o < soup.objStart.size(); ++o) {
+            const uint32_t t0 = soup.objStart[o];
+            const uint32_t t1 = o + 1 < soup.objStart.size() ? soup.objStart[o + 1] : soup.numTris();
+            appendObject(soup.pos.data() + 9 * (size_t)t0, soup.uv.data() + 6 * (size_t)t0, t1 - t0, mat);
+        }
         if (mat < 0 && !soup.mtlNames.empty()) {
             std::vector<MtlMaterial> lib;
             for (const std::string &ml : soup.mtlLibs) {
@@ -1047,6 +1052,9 @@ void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dt
     case MRX_BUF_INSTANCE_SCALE:
         dims[0] = I; dims[1] = 3; *ndim = 2; *dtype = MRX_DTYPE_F32; ptr = r->instScale.ptr;
         break;
+    case MRX_BUF_INSTANCE_OBJECT:     // ObjectID column (sim.cpp:152-156); negative = hidden
+        dims[0] = I; *ndim = 1; *dtype = MRX_DTYPE_I32; ptr = r->instObj.ptr;
+        break;
     // The reference sizes the camera tensors with totalNumInstances
     // (mgr.cpp:652,662); the rows that exist are one per camera, exported so.
     case MRX_BUF_CAMERA_POSITION:
@@ -1165,6 +1173,19 @@ int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv, uint32_t *nu
     std::memcpy(*tri_pos, soup.pos.data(), soup.pos.size() * sizeof(float));
     std::memcpy(*tri_uv, soup.uv.data(), soup.uv.size() * sizeof(float));
     return MRX_OK;
+}
+
+int mrx_obj_objects(const char *path, uint32_t *first_tri, uint32_t capacity)
+{
+    if (!path || (!first_tri && capacity))
+        return fail(MRX_E_INVALID, "null argument");
+    mrx::TriSoup soup;
+    std::string err;
+    if (!mrx::loadOBJ(path, soup, err))
+        return fail(MRX_E_ASSET, err);
+    for (size_t o = 0; o < soup.objStart.size() && o < capacity; ++o)
+        first_tri[o] = soup.objStart[o];
+    return (int)soup.objStart.size();
 }
 
 int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width, uint32_t *height)

@@ -303,6 +303,10 @@ PYBIND11_MODULE(madrona_renderer, m)
              [](py::object self) {
                  return wrapTensor(self, self.cast<Manager &>().instancePositionTensor());
              })
+        .def("instance_object_tensor",
+             [](py::object self) {
+                 return wrapTensor(self, self.cast<Manager &>().instanceObjectTensor());
+             })
         .def("instance_rotation_tensor",
              [](py::object self) {
                  return wrapTensor(self, self.cast<Manager &>().instanceRotationTensor());

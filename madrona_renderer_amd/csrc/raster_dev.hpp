@@ -165,7 +165,8 @@ __device__ __forceinline__ bool setupTriangleCore(const RasterParams &p, const f
     const float d = dot3(nn[0], nn[1], nn[2], P[0][0], P[0][1], P[0][2]);
     // S6: degenerate / edge-on triangles; S6b: faces of a closed object turned
     // away from an eye outside the object can never be the nearest hit
-    const bool valid = fabsf(d) > 0.0f && !(cullBack && d > 0.0f) && !(cullFront && d < 0.0f);
+    // (an instance whose ObjectID is negative this step is hidden: MRX_BUF_INSTANCE_OBJECT)
+    const bool valid = obj >= 0 && fabsf(d) > 0.0f && !(cullBack && d > 0.0f) && !(cullFront && d < 0.0f);
 
     // Binning aid: pixel-space bounding box of the projected vertices, padded
     // by a pixel plus a relative margin that swallows the rounding of the

@@ -55,6 +55,7 @@ class _Scene(ctypes.Structure):
         ("num_textures", ctypes.c_int32),
         ("inst_pos", ctypes.c_void_p), ("inst_rot", ctypes.c_void_p),
         ("inst_scale", ctypes.c_void_p), ("inst_obj", ctypes.c_void_p),
+        ("inst_obj0", ctypes.c_void_p),
         ("world_inst_start", ctypes.c_void_p),
         ("cam_pos", ctypes.c_void_p), ("cam_rot", ctypes.c_void_p),
         ("view_world", ctypes.c_void_p), ("num_views", ctypes.c_int32),
@@ -99,20 +100,26 @@ def lib():
 # --------------------------------------------------------------------------
 # independent asset readers
 # --------------------------------------------------------------------------
-def parse_obj(path, with_materials=False):
+def parse_obj(path, with_materials=False, with_objects=False):
     """Wavefront OBJ -> (tri_pos [T,3,3] f32, tri_uv [T,3,2] f32).
 
-    One object per file; polygons fan-triangulated; ``vt`` optional.  With
-    ``with_materials`` also returns (tri_mtl [T] index into names or -1, names,
-    mtllib paths resolved against the OBJ's directory)."""
+    Polygons fan-triangulated; ``vt`` optional.  With ``with_materials`` also
+    returns (tri_mtl [T] index into names or -1, names, mtllib paths resolved
+    against the OBJ's directory); with ``with_objects`` the first triangle of
+    each object last -- one object per ``o`` / ``g`` block that holds faces
+    (/root/reference/src/mgr.cpp:294-307 receives ImportedAssets::objects)."""
     vs, vts, tris_p, tris_t = [], [], [], []
     tri_mtl, names, libs, cur = [], [], [], -1
+    obj_start = [0]
     base = os.path.dirname(path)
     with open(path, "r") as f:
         for line in f:
             parts = line.split()
             if not parts:
                 continue
+            if parts[0] in ("o", "g"):
+                if len(tris_p) > obj_start[-1]:
+                    obj_start.append(len(tris_p))
             if parts[0] == "usemtl" and len(parts) > 1:
                 name = line.split(None, 1)[1].strip()
                 if name not in names:
@@ -144,9 +151,12 @@ def parse_obj(path, with_materials=False):
                     tri_mtl.append(cur)
     pos = np.asarray(tris_p, dtype=np.float64).astype(np.float32).reshape(-1, 3, 3)
     uv = np.asarray(tris_t, dtype=np.float64).astype(np.float32).reshape(-1, 3, 2)
+    out = (pos, uv)
     if with_materials:
-        return pos, uv, np.asarray(tri_mtl, dtype=np.int32), names, libs
-    return pos, uv
+        out += (np.asarray(tri_mtl, dtype=np.int32), names, libs)
+    if with_objects:
+        out += (obj_start,)
+    return out
 
 
 def parse_mtl(path):
@@ -285,7 +295,8 @@ class FlatScene:
         mats = list(desc.materials)
         file_mats = []              # (Kd, map_Kd) appended after the API materials
         for path, mat_id in desc.asset_paths:
-            p, t, tri_mtl, names, libs = parse_obj(_path(path), with_materials=True)
+            p, t, tri_mtl, names, libs, starts = parse_obj(_path(path), with_materials=True,
+                                                           with_objects=True)
             pos_l.append(p)
             uv_l.append(t)
             # intended semantics of the disabled block mgr.cpp:339-349: mat_id
@@ -306,8 +317,10 @@ class FlatScene:
                     if k >= 0:
                         tm[i] = name_to_mat[k]
             mat_l.append(tm)
-            first.append(ntri)
-            count.append(len(p))
+            for o, t0 in enumerate(starts):       # one object per `o` / `g` block
+                t1 = starts[o + 1] if o + 1 < len(starts) else len(p)
+                first.append(ntri + t0)
+                count.append(t1 - t0)
             ntri += len(p)
         verts = np.asarray(desc.mesh_vertices, dtype=np.float32).reshape(-1, 3)
         uvs = np.asarray(desc.mesh_uvs, dtype=np.float32).reshape(-1, 2)
@@ -404,6 +417,9 @@ class FlatScene:
         self.inst_rot = np.asarray(irot, dtype=np.float32).reshape(-1, 4)
         self.inst_scale = np.asarray(iscl, dtype=np.float32).reshape(-1, 3)
         self.inst_obj = np.asarray(iobj, dtype=np.int32)
+        # ObjectID at creation binds geometry and triangle slots; tests hide an
+        # instance by writing a negative id into inst_obj afterwards
+        self.inst_obj0 = self.inst_obj.copy()
         self.world_inst_start = np.asarray(wstart, dtype=np.int32)
         self.cam_pos = np.asarray(cpos, dtype=np.float32).reshape(-1, 3)
         self.cam_rot = np.asarray(crot, dtype=np.float32).reshape(-1, 4)
@@ -431,6 +447,7 @@ class FlatScene:
         s.num_textures = self.num_textures
         s.inst_pos = ptr(self.inst_pos); s.inst_rot = ptr(self.inst_rot)
         s.inst_scale = ptr(self.inst_scale); s.inst_obj = ptr(self.inst_obj)
+        s.inst_obj0 = ptr(self.inst_obj0)
         s.world_inst_start = ptr(self.world_inst_start)
         s.cam_pos = ptr(self.cam_pos); s.cam_rot = ptr(self.cam_rot)
         s.view_world = ptr(self.view_world)

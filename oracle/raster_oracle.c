@@ -66,7 +66,9 @@ typedef struct {
     const float   *inst_pos;       /* [I][3]                                  */
     const float   *inst_rot;       /* [I][4] w,x,y,z                          */
     const float   *inst_scale;     /* [I][3]                                  */
-    const int32_t *inst_obj;       /* [I]                                     */
+    const int32_t *inst_obj;       /* [I] ObjectID now: negative = hidden     */
+    const int32_t *inst_obj0;      /* [I] ObjectID at creation: binds the geometry and the
+                                    * world-local triangle slots (MRX_BUF_INSTANCE_OBJECT) */
     const int32_t *world_inst_start; /* [W+1] prefix sum of numInstances      */
     const float   *cam_pos;        /* [V][3]                                  */
     const float   *cam_rot;        /* [V][4]                                  */
@@ -143,9 +145,13 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
 
     int n = 0, k = 0;
     for (int i = s->world_inst_start[w]; i < s->world_inst_start[w + 1]; ++i) {
-        const int obj = s->inst_obj[i];
+        const int obj = s->inst_obj0[i];
         if (obj < 0 || obj >= s->num_objects)
             continue;
+        if (s->inst_obj[i] < 0) {                 /* hidden this step: its slots stay empty */
+            k += s->obj_num_tris[obj];
+            continue;
+        }
         float Ri[3][3], M[3][3], MV[3][3], tv[3];
         quat_to_mat(&s->inst_rot[4 * i], Ri);
         const float *sc = &s->inst_scale[3 * i];
@@ -246,7 +252,7 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
             o->rgba = to_u8(o->lit[0]) | (to_u8(o->lit[1]) << 8) |
                       (to_u8(o->lit[2]) << 16) | 0xFF000000u;
             o->tex = tex;
-            o->seg = obj;
+            o->seg = s->inst_obj[i];
             o->k = k;
         }
     }
@@ -259,7 +265,7 @@ static int max_world_tris(const orc_scene *s)
     for (int v = 0; v < s->num_views; ++v) {
         int w = s->view_world[v], cnt = 0;
         for (int i = s->world_inst_start[w]; i < s->world_inst_start[w + 1]; ++i) {
-            int obj = s->inst_obj[i];
+            int obj = s->inst_obj0[i];
             if (obj >= 0 && obj < s->num_objects)
                 cnt += s->obj_num_tris[obj];
         }

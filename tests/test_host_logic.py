@@ -245,3 +245,52 @@ def test_shard_ranges_partition_the_worlds():
     d = scenes.synthetic_scene(10)
     s = d.shard(1, 4)
     assert s.num_worlds == 3 and s.worlds == d.worlds[3:6]
+
+
+MULTI_OBJ = """# three objects: a quad, a triangle fan, and one more quad; blocks without faces open nothing
+v 0 0 0
+v 1 0 0
+v 1 0 1
+v 0 0 1
+o first
+f 1 2 3 4
+g
+o second
+v 2 0 0
+v 3 0 0
+v 3 0 1
+v 2 0 1
+v 2.5 0 2
+f 5 6 7 8 9
+o empty_block
+g third
+f -5 -4 -1
+f 1 2 3
+"""
+
+
+def test_obj_files_yield_one_object_per_block(native, oracle_mod, tmp_path):
+    # /root/reference/src/mgr.cpp:294-307: importFromDisk hands back objects
+    # (plural) per file; here one per `o` / `g` block that holds faces
+    path = tmp_path / "multi.obj"
+    path.write_text(MULTI_OBJ)
+    lib = native.load_capi()
+    first = (ctypes.c_uint32 * 8)()
+    n = lib.mrx_obj_objects(str(path).encode(), first, 8)
+    assert n == 3 and list(first[:3]) == [0, 2, 5]
+    pos, uv, starts = oracle_mod.parse_obj(str(path), with_objects=True)
+    assert starts == [0, 2, 5] and len(pos) == 7
+    rc, cpos, _ = _load_obj(lib, str(path))
+    assert rc == 0 and np.array_equal(cpos, pos)
+    # the files of data/ hold one block each
+    assert lib.mrx_obj_objects(os.path.join(scenes.DATA_DIR, "cube.obj").encode(), first, 8) == 1
+    # in a scene: the file's objects take ids 0..2, the next asset id 3, the raw mesh id 4
+    d = scenes.SceneDesc(
+        num_worlds=1, asset_paths=[(str(path), -1), (os.path.join(scenes.DATA_DIR, "plane.obj"), -1)],
+        mesh_vertices=np.zeros((3, 3), np.float32), mesh_uvs=np.zeros((3, 2), np.float32),
+        mesh_indices=np.arange(3, dtype=np.uint32), mesh_vertex_offsets=np.zeros(1, np.uint32),
+        mesh_indices_offsets=np.zeros(1, np.uint32), mesh_materials=np.array([-1], np.int32),
+        instances=[((0.0, 3.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 2)],
+        cameras=[((0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0))], worlds=[(1, 0, 1, 0)])
+    fs = oracle_mod.FlatScene(d)
+    assert fs.obj_first_tri.tolist() == [0, 2, 5, 7, 9] and fs.obj_num_tris.tolist() == [2, 3, 2, 2, 1]

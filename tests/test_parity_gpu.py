@@ -447,6 +447,73 @@ def test_obj_materials_from_mtl(native, tmp_path):
     assert len(colours) > 10                      # textured faces show many texel colours
 
 
+def test_multi_object_obj_numbers_objects_per_block(native, tmp_path):
+    # one object per `o` / `g` block (mgr.cpp:294-307): instances address them by
+    # id, later assets and raw meshes are numbered after them
+    from tests.test_host_logic import MULTI_OBJ
+    path = tmp_path / "multi.obj"
+    path.write_text(MULTI_OBJ)
+    q = (0.7071068, 0.7071068, 0.0, 0.0)
+    for mode in ("Rasterizer", "Raytracer"):
+        d = scenes.SceneDesc(
+            num_worlds=2, width=64, height=64, render_mode=mode,
+            asset_paths=[(str(path), 0), (CUBE, 1)],
+            materials=[((0.9, 0.2, 0.2, 1.0), -1, 0.5, 0.5), ((0.2, 0.9, 0.2, 1.0), -1, 0.5, 0.5)],
+            instances=[((-2.0, 6.0, -1.0), IDENT, (1.0, 1.0, 1.0), 0), ((-1.0, 6.0, -1.0), IDENT, (1.0, 1.0, 1.0), 1),
+                       ((-1.5, 6.5, 0.5), IDENT, (1.0, 1.0, 1.0), 2), ((2.0, 7.0, 0.0), q, (1.5, 1.5, 1.5), 3),
+                       ((0.0, 5.0, 1.0), IDENT, (1.0, 1.0, 1.0), 4)],       # 4: no such object
+            cameras=[((0.0, 0.0, 0.0), IDENT)], worlds=[(5, 0, 1, 0), (2, 1, 1, 0)])
+        r = make_product(d, visibility=False)
+        got = fetch(r, visibility=False, raytracer=(mode == "Raytracer"))
+        ref = render_oracle(d)
+        assert_parity(got, ref)
+        if mode == "Raytracer":
+            assert set(np.unique(ref["segmask"][0]).tolist()) == {-1, 0, 1, 2, 3}
+
+
+@pytest.mark.parametrize("kind", ["uniform", "ragged", "bvh"])
+def test_instances_hidden_and_shown_between_steps(native, kind):
+    # f4 (/root/reference/src/sim.inl:5-16): a negative ObjectID hides the instance from
+    # the next step on, the id written back shows it again; triangle slots (and
+    # with them the visibility ids of everything else) stay where they are
+    import torch
+    from tests import meshes
+    from oracle import oracle
+    if kind == "uniform":
+        d = scenes.synthetic_scene(70, with_wall=True, textured=True)       # the arithmetic draw list
+    elif kind == "ragged":
+        d = scenes.synthetic_scene(12, with_wall=True)
+        d.worlds = [(3, 3 * w, 1, w) if w % 3 else (2, 3 * w, 1, w) for w in range(12)]
+    else:
+        d = meshes.cube_field(num_worlds=5, cubes=30, textured=True)        # 362 triangles: BVH path
+    r = make_product(d, visibility=True)
+    fs = oracle.FlatScene(d)
+    obj = r.instance_object_tensor().to_torch()
+    assert obj.dtype == torch.int32 and tuple(obj.shape) == (len(fs.inst_obj),) and obj.is_cuda
+    assert np.array_equal(obj.cpu().numpy(), fs.inst_obj)
+    rng = np.random.default_rng(5)
+    first = None
+    for step in range(4):
+        hide = rng.random(len(fs.inst_obj)) < (0.5 if step < 3 else 0.0)    # last step: all back
+        now = np.where(hide, -1 - fs.inst_obj0, fs.inst_obj0).astype(np.int32)
+        obj.copy_(torch.from_numpy(now).to(obj.device))
+        r.step()
+        fs.inst_obj[:] = now
+        got, ref = fetch(r), fs.render()
+        assert_parity(got, ref)
+        first = ref if first is None else first
+        assert step == 3 or not np.array_equal(ref["tri_id"], full_ids(fs))
+    assert np.array_equal(got["tri_id"], full_ids(fs))
+
+
+def full_ids(fs):
+    keep = fs.inst_obj.copy()
+    fs.inst_obj[:] = fs.inst_obj0
+    out = fs.render()["tri_id"]
+    fs.inst_obj[:] = keep
+    return out
+
+
 def test_zero_worlds_and_zero_views(native):
     d = scenes.synthetic_scene(2)
     d.worlds = []
