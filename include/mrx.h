@@ -222,6 +222,13 @@ int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv,
 int mrx_obj_objects(const char *path, uint32_t *first_tri, uint32_t capacity);
 int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width,
                    uint32_t *height);
+/*    Texture files as mrx_create reads them: .ktx2 (BC7 or RGBA8 base level,
+ *    decoded to RGBA8 on the host -- the reference's "ktx2" handler,
+ *    /root/reference/src/mgr.cpp:199-212,297-298) or PNG. */
+int mrx_decode_texture(const char *path, uint8_t **rgba, uint32_t *width,
+                       uint32_t *height);
+/*    BC7 blocks (16 bytes each) -> RGBA8, 16 pixels per block, row-major in the block. */
+int mrx_decode_bc7(const uint8_t *blocks, uint32_t num_blocks, uint8_t *rgba /*[num_blocks][16][4]*/);
 /*    What the OBJ reader makes of a file's material statements, as JSON text:
  *    {"num_tris":N,"tri_mtl":[...],"names":[...],"libs":[...],
  *     "materials":[{"name":..,"kd":[r,g,b],"map_kd":..},...]} (materials = every

@@ -18,8 +18,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["raster.hip", "bvh.hip", "bvh.cpp", "mrx_api.cpp", "assets.cpp"]
-HIP_DEPS = HIP_SOURCES + ["raster.hpp", "raster_dev.hpp", "bvh.hpp", "assets.hpp",
+HIP_SOURCES = ["raster.hip", "bvh.hip", "bvh.cpp", "mrx_api.cpp", "assets.cpp", "ktx2.cpp"]
+HIP_DEPS = HIP_SOURCES + ["raster.hpp", "raster_dev.hpp", "bvh.hpp", "assets.hpp", "bc7_tables.inc",
                           "../../include/mrx.h"]
 MGR_SOURCES = ["manager.cpp"]
 MGR_DEPS = MGR_SOURCES + ["../../include/madrona_mi355/manager.hpp",
@@ -122,7 +122,7 @@ def build_headless(force=False, verbose=False):
         cmd = ["g++", "-O2", "-std=c++17", "-Wall",
                "-DMRX_DATA_DIR=\"%s\"" % os.path.join(ROOT, "data"),
                os.path.join(CSRC, "headless.cpp"), os.path.join(CSRC, "manager.cpp"),
-               os.path.join(CSRC, "assets.cpp"),
+               os.path.join(CSRC, "assets.cpp"), os.path.join(CSRC, "ktx2.cpp"),
                "-L" + HERE, "-lmrx_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", out]
         _run(cmd, verbose)
     return out

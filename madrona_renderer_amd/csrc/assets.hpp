@@ -43,6 +43,13 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err);
 bool loadMTL(const std::string &path, std::vector<MtlMaterial> &out, std::string &err);
 bool decodePNG(const std::string &path, Image &out, std::string &err);
 bool decodePNGMem(const uint8_t *data, size_t size, Image &out, std::string &err);
+// KTX2 container with a BC7 or RGBA8 base level -> RGBA8 (ktx2.cpp; the
+// reference's "ktx2" handler, /root/reference/src/mgr.cpp:199-212,297-298).
+bool decodeKTX2(const std::string &path, Image &out, std::string &err);
+bool decodeKTX2Mem(const uint8_t *data, size_t size, Image &out, std::string &err);
+void decodeBC7Block(const uint8_t block[16], uint8_t out[16][4]);
+// By extension: .ktx2 -> decodeKTX2, anything else -> decodePNG.
+bool decodeTexture(const std::string &path, Image &out, std::string &err);
 // 8-bit RGBA, non-interlaced, zlib-deflated, filter type 0 on every scanline.
 bool encodePNG(const std::string &path, const uint8_t *rgba, uint32_t width, uint32_t height,
                std::string &err);

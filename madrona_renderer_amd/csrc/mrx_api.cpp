@@ -393,7 +393,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     for (uint32_t t = 0; t < cfg.num_textures; ++t) {
         Image img;
         std::string err;
-        if (!decodePNG(cfg.texture_paths[t], img, err))
+        if (!decodeTexture(cfg.texture_paths[t], img, err))
             return fail(MRX_E_ASSET, "Failed to load texture: " + err);
         TexDesc d {};
         d.offset = (uint32_t)texels.size();
@@ -405,7 +405,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         std::memcpy(texels.data() + d.offset, img.rgba.data(), n * 4);
     }
     // combined material table: API materials, then file materials whose map_Kd
-    // textures (PNG only; anything unreadable means untextured) follow the API textures
+    // textures (PNG or KTX2; anything unreadable means untextured) follow the API textures
     std::vector<mrx_material> allMats(cfg.materials, cfg.materials + cfg.num_materials);
     for (const FileMat &fm : fileMats) {
         mrx_material m {};
@@ -421,7 +421,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             if (found < 0) {
                 Image img;
                 std::string terr;
-                if (decodePNG(fm.mapKd, img, terr)) {
+                if (decodeTexture(fm.mapKd, img, terr)) {
                     TexDesc d {};
                     d.offset = (uint32_t)texels.size();
                     d.width = img.width;
@@ -1200,6 +1200,30 @@ int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width, uint32_t *
     *height = img.height;
     *rgba = (uint8_t *)std::malloc(img.rgba.size() + 4);
     std::memcpy(*rgba, img.rgba.data(), img.rgba.size());
+    return MRX_OK;
+}
+
+int mrx_decode_texture(const char *path, uint8_t **rgba, uint32_t *width, uint32_t *height)
+{
+    if (!path || !rgba || !width || !height)
+        return fail(MRX_E_INVALID, "null argument");
+    mrx::Image img;
+    std::string err;
+    if (!mrx::decodeTexture(path, img, err))
+        return fail(MRX_E_ASSET, err);
+    *width = img.width;
+    *height = img.height;
+    *rgba = (uint8_t *)std::malloc(img.rgba.size() + 4);
+    std::memcpy(*rgba, img.rgba.data(), img.rgba.size());
+    return MRX_OK;
+}
+
+int mrx_decode_bc7(const uint8_t *blocks, uint32_t num_blocks, uint8_t *rgba)
+{
+    if ((!blocks || !rgba) && num_blocks)
+        return fail(MRX_E_INVALID, "null argument");
+    for (uint32_t b = 0; b < num_blocks; ++b)
+        mrx::decodeBC7Block(blocks + 16 * (size_t)b, reinterpret_cast<uint8_t (*)[4]>(rgba + 64 * (size_t)b));
     return MRX_OK;
 }
 

@@ -242,8 +242,49 @@ def shell_orientation(tri_pos):
     return orient, bmin, bmax
 
 
+def _dds_bc7(blocks, w, h):
+    """BC7 blocks wrapped as an in-memory DDS file (DX10 header, DXGI_FORMAT_BC7_UNORM)."""
+    import struct
+    hdr = b"DDS " + struct.pack("<7I", 124, 0x1007 | 0x80000, h, w, len(blocks), 0, 1) + bytes(44)
+    hdr += struct.pack("<2I4s5I", 32, 0x4, b"DX10", 0, 0, 0, 0, 0)
+    hdr += struct.pack("<5I", 0x1000, 0, 0, 0, 0)
+    return hdr + struct.pack("<5I", 98, 3, 0, 1, 0) + blocks
+
+
+def decode_bc7(blocks, width, height):
+    """BC7 blocks -> RGBA8 [height, width, 4] through Pillow's DDS reader."""
+    import io
+    from PIL import Image
+    bw, bh = (width + 3) // 4, (height + 3) // 4
+    with Image.open(io.BytesIO(_dds_bc7(bytes(blocks), bw * 4, bh * 4))) as im:
+        return np.asarray(im.convert("RGBA"), dtype=np.uint8)[:height, :width].copy()
+
+
+def decode_ktx2(path):
+    """KTX 2.0 (BC7 or RGBA8 base level, supercompression none / ZLIB) -> RGBA8.
+    An independent reading of the container (struct) and of BC7 (Pillow)."""
+    import struct
+    import zlib
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:12] != bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x32, 0x30, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A]):
+        raise OSError("not a KTX2 file")
+    vk, _ts, w, h, d, layers, faces, levels, scheme = struct.unpack_from("<9I", data, 12)
+    off, length, _ulen = struct.unpack_from("<3Q", data, 80)
+    if d > 1 or layers > 1 or faces != 1 or vk not in (37, 43, 145, 146) or scheme not in (0, 3):
+        raise OSError("unsupported KTX2")
+    payload = data[off:off + length]
+    if scheme == 3:
+        payload = zlib.decompress(payload)
+    if vk in (37, 43):
+        return np.frombuffer(payload[:w * h * 4], np.uint8).reshape(h, w, 4).copy()
+    return decode_bc7(payload[:((w + 3) // 4) * ((h + 3) // 4) * 16], w, h)
+
+
 def decode_image(path):
-    """Image file -> RGBA8 array [h, w, 4] (Pillow)."""
+    """Image file -> RGBA8 array [h, w, 4]: .ktx2 as above, the rest by Pillow."""
+    if path.lower().endswith(".ktx2"):
+        return decode_ktx2(path)
     from PIL import Image
     with Image.open(path) as im:
         return np.asarray(im.convert("RGBA"), dtype=np.uint8).copy()
@@ -382,8 +423,8 @@ class FlatScene:
             if map_kd:
                 if map_kd not in file_tex:
                     try:
-                        if not map_kd.lower().endswith(".png"):
-                            raise OSError("only PNG textures are read")
+                        if not map_kd.lower().endswith((".png", ".ktx2")):
+                            raise OSError("only PNG and KTX2 textures are read")
                         img = decode_image(map_kd)
                         file_tex[map_kd] = len(texels)
                         add_texture(img)
