@@ -426,19 +426,16 @@ void bvhTileKernel(const RasterParams p)
                     x.sc[0] = a4.x; x.sc[1] = a4.y; x.sc[2] = a4.z;
                     const int32_t obj = __float_as_int(a4.w);
                     const uint32_t k = __float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y));
-                    float shade[4], cold[kCold];
+                    const uint32_t slot = slotBase + (uint32_t)lane;
+                    // (textured variant: the u/v planes and the lit colour go straight to the
+                    // lane's reserved record; untextured triangles are packed to RGBA8 here)
+                    float shade[4], coldLocal[kCold];
+                    float *cold = TEX ? coldTab[slot] : coldLocal;
                     const bool valid = setupTriangleCore(p, vc.lv, x, e.y, obj, (int32_t)k, c, shade, cold);
                     live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
-                    const uint32_t slot = slotBase + (uint32_t)lane;
                     lowKey = ((~k & kKeyMask) << kSlotBits) | slot;
-                    if (live) {
+                    if (live)
                         shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(obj), __uint_as_float(k));
-                        if (TEX && __float_as_int(shade[1]) >= 0) {
-#pragma unroll
-                            for (int i = 0; i < 9; ++i)
-                                coldTab[slot][i] = cold[i];
-                        }
-                    }
                 }
                 if (p.debugSkip & 128u) MRX_STAMP(3);
                 // pixel range of the triangle inside the tile: the conservative box
