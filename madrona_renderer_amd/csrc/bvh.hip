@@ -434,8 +434,9 @@ void bvhTileKernel(const RasterParams p)
                     const bool valid = setupTriangleCore(p, vc.lv, x, e.y, obj, (int32_t)k, c, shade, cold);
                     live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
                     lowKey = ((~k & kKeyMask) << kSlotBits) | slot;
-                    if (live)
-                        shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(obj), __uint_as_float(k));
+                    // (written for dead triangles too: the slot's previous tenant must not be
+                    // matched against the u/v planes just stored over its own)
+                    shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(obj), __uint_as_float(k));
                 }
                 if (p.debugSkip & 128u) MRX_STAMP(3);
                 // pixel range of the triangle inside the tile: the conservative box
