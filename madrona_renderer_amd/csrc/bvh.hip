@@ -38,7 +38,6 @@
 namespace mrx {
 namespace {
 
-constexpr int kBvhWaves = 8;            // one wave per 64x8 strip of the tile
 constexpr int kQueueCap = 64 + 32;      // a flush takes 64; one append adds <= 32
 constexpr int kInstRecDw = 24;          // MV[9] tv[3] qo[3] det sc[3] obj kBase firstTri numTris root
 
@@ -110,10 +109,12 @@ constexpr int kSlotBits = 10;
 constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kBigRound = 8;                    // in-wave fallback: large triangles per round
-constexpr int kBigCap = 96;                     // shared list of large triangles per round of the tile
 
 
-template <bool TEX> constexpr int tabCap() { return TEX ? 256 : 1024; }
+// Tile shapes (the LDS tile-size sweep of BASELINE configs[2]): TW x TH pixels per workgroup, one wave per
+// TW x 8 strip, so TH / 8 waves; the depth buffer takes TW * TH * 8 bytes of LDS.
+constexpr int tabCap(bool tex, int tw, int th) { return tex ? 256 : (tw * th >= 4096 ? 1024 : 512); }
+constexpr int bigCap(int tw, int th) { return tw * th >= 4096 ? 96 : 48; }
 
 struct WaveScratch {
     // (instance of the pass, object triangle).  Once a batch is set up, the
@@ -146,18 +147,23 @@ __device__ __forceinline__ void pixelTestKey(const PlanePairs &q, f32x2 r01, f32
 
 // IDS: 0 = no id tensor, 1 = visibility ids (world-local triangle index),
 // 2 = segmask (objectID of the winner's instance)
-template <int IDS, bool TEX>
-__global__ __launch_bounds__(kWave *kBvhWaves, 4)
+template <int IDS, bool TEX, int TW, int TH>
+__global__ __launch_bounds__(kWave *(TH / 8), 4)
 void bvhTileKernel(const RasterParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int kCap = tabCap<TEX>();
+    constexpr int kBvhWaves = TH / 8;             // one wave per TW x 8 strip of the tile
+    constexpr int kHalves = TW / 32;              // 32-pixel halves of a strip: 4 pixels of a lane each
+    constexpr int kCap = tabCap(TEX, TW, TH);
+    constexpr int kBigCap = bigCap(TW, TH);
+    static_assert((TW == 64 || TW == 32) && (TH == 64 || TH == 32), "tile shapes of the sweep");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
-    const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
+    const uint32_t tilesFast = (p.nfast + TW - 1) / TW, tilesSlow = (p.nslow + TH - 1) / TH;
+    const uint32_t tilesPerView = tilesFast * tilesSlow;
     const uint32_t view = blockIdx.x / tilesPerView;
     const uint32_t tile = blockIdx.x - view * tilesPerView;
-    const uint32_t tileX0 = (tile % p.tilesFast) * 64u, tileY0 = (tile / p.tilesFast) * 64u;
+    const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
     const uint32_t passInst = p.bvhPassInst;
     if (p.debugSkip & 16u)
         return;                                       // timing aid: bare launch
@@ -173,8 +179,8 @@ void bvhTileKernel(const RasterParams p)
 
     // ---- LDS: depth buffer of the tile, shading records of the pass, control
     //      words, the TLAS of the pass, per-wave scratch
-    unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [64][64]
-    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + 4096);                         // [kCap] rgba tex obj k
+    unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [TH][TW]
+    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + TW * TH);                         // [kCap] rgba tex obj k
     float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [4]
     float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 4);                   // [kBigCap] planes, key, box
@@ -209,11 +215,11 @@ void bvhTileKernel(const RasterParams p)
     }
     const float isx = __builtin_amdgcn_rcpf(p.sx), isz = __builtin_amdgcn_rcpf(p.sz);
     const float invNear = p.invNear, invFar = p.invFar;
-    const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + 63u);
-    const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + 63u);
+    const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
+    const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
     const int smallArea = p.bvhSmallArea;
 
-    for (int i = threadIdx.x; i < 4096; i += kWave * kBvhWaves)
+    for (int i = threadIdx.x; i < TW * TH; i += kWave * kBvhWaves)
         zbuf[i] = packHit(invFar, 0u);
     if (threadIdx.x == 0)
         ctrl[0] = ctrl[1] = ctrl[2] = 0u;          // records, waves that are done, large triangles
@@ -221,10 +227,10 @@ void bvhTileKernel(const RasterParams p)
     // the lane's pixels at output time: strip = wave, four consecutive pixels of
     // one row in each 32-pixel half (one 16-byte store per tensor and half)
     const int lx = lane & 7, ly = lane >> 3;
-    uint32_t rgba[2][kRegionBlocks];
-    int32_t seg[2][kRegionBlocks];
+    uint32_t rgba[kHalves][kRegionBlocks];
+    int32_t seg[kHalves][kRegionBlocks];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+    for (int hf = 0; hf < kHalves; ++hf)
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
             rgba[hf][b] = 0xFF000000u;
@@ -337,7 +343,7 @@ void bvhTileKernel(const RasterParams p)
                             }
                             const Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
                             // the root's children are dealt one per wave
-                            const bool hit = cref != kBvhEmpty && corner == 0 && (!isRoot || c == wave) &&
+                            const bool hit = cref != kBvhEmpty && corner == 0 && (!isRoot || (c & (kBvhWaves - 1)) == wave) &&
                                              overlaps(r, TX0, TX1, TY0, TY1);
                             uint64_t hm = __ballot(hit);
                             while (hm) {
@@ -395,25 +401,18 @@ void bvhTileKernel(const RasterParams p)
                     break;
                 waveLdsSync();                        // the queue entries written above are read below
 
-                // -- a batch of up to 64 candidates: reserve shading records
+                // -- a batch of up to 64 candidates.  Leaf test setup, lane = triangle:
+                //    S3-S7 with the instance's transform from the TLAS record.
                 const uint32_t nb = qCount < (uint32_t)kWave ? qCount : (uint32_t)kWave;
                 if (p.debugSkip & 128u) MRX_STAMP(2);
-                uint32_t slotBase = 0;
-                if (lane == 0)
-                    slotBase = atomicAdd(&ctrl[0], nb);
-                slotBase = rflu(slotBase);
-                if (slotBase + nb > (uint32_t)kCap) {
-                    tableFull = true;                 // wait for the resolve, then take the batch again
-                    break;
-                }
-                // -- leaf test setup.  Lane = triangle: S3-S7 with the instance's
-                //    transform from the TLAS record.
                 bool live = false;
                 TriPlanes c;
                 c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
                 c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
                 c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
-                uint32_t lowKey = 0;
+                uint32_t kTri = 0;
+                int32_t objL = -1;
+                float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
                 if ((uint32_t)lane < nb && !(p.debugSkip & 8u)) {
                     const uint2 e = ws->queue[lane];
                     const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)e.x * kInstRecDw);
@@ -424,19 +423,32 @@ void bvhTileKernel(const RasterParams p)
                     x.MV[2][2] = a2.x; x.tv[0] = a2.y; x.tv[1] = a2.z; x.tv[2] = a2.w;
                     x.qo[0] = a3.x; x.qo[1] = a3.y; x.qo[2] = a3.z; x.det = a3.w;
                     x.sc[0] = a4.x; x.sc[1] = a4.y; x.sc[2] = a4.z;
-                    const int32_t obj = __float_as_int(a4.w);
-                    const uint32_t k = __float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y));
-                    const uint32_t slot = slotBase + (uint32_t)lane;
-                    // (textured variant: the u/v planes and the lit colour go straight to the
-                    // lane's reserved record; untextured triangles are packed to RGBA8 here)
-                    float shade[4], coldLocal[kCold];
-                    float *cold = TEX ? coldTab[slot] : coldLocal;
-                    const bool valid = setupTriangleCore(p, vc.lv, x, e.y, obj, (int32_t)k, c, shade, cold);
+                    objL = __float_as_int(a4.w);
+                    kTri = __float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y));
+                    const bool valid = setupTriangleCore(p, vc.lv, x, e.y, objL, (int32_t)kTri, c, shade, cold);
                     live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
-                    lowKey = ((~k & kKeyMask) << kSlotBits) | slot;
-                    // (written for dead triangles too: the slot's previous tenant must not be
-                    // matched against the u/v planes just stored over its own)
-                    shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(obj), __uint_as_float(k));
+                }
+                // -- shading records only for triangles that can own a pixel of the tile
+                //    (about half the candidates are back faces): slots by rank among them
+                const uint64_t liveMask = __ballot(live);
+                const uint32_t numLive = (uint32_t)__builtin_popcountll(liveMask);
+                uint32_t slotBase = 0;
+                if (lane == 0 && numLive)
+                    slotBase = atomicAdd(&ctrl[0], numLive);
+                slotBase = rflu(slotBase);
+                if (slotBase + numLive > (uint32_t)kCap) {
+                    tableFull = true;                 // wait for the resolve, then take the batch again
+                    break;
+                }
+                const uint32_t slot = slotBase + (uint32_t)__builtin_popcountll(liveMask & ((1ull << lane) - 1ull));
+                const uint32_t lowKey = ((~kTri & kKeyMask) << kSlotBits) | slot;
+                if (live) {
+                    shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(objL), __uint_as_float(kTri));
+                    if (TEX && __float_as_int(shade[1]) >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i)
+                            coldTab[slot][i] = cold[i];
+                    }
                 }
                 if (p.debugSkip & 128u) MRX_STAMP(3);
                 // pixel range of the triangle inside the tile: the conservative box
@@ -466,7 +478,7 @@ void bvhTileKernel(const RasterParams p)
                                 const f32x2 yy = { py, py };
                                 const f32x2 r01 = fma2(B01, yy, C01);
                                 const f32x2 r2d = fma2(B2D, yy, C2D);
-                                unsigned long long *zrow = zbuf + (sy - (int)tileY0) * 64 + (sx - (int)tileX0);
+                                unsigned long long *zrow = zbuf + (sy - (int)tileY0) * TW + (sx - (int)tileX0);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     const float px = (float)(sx + j);
@@ -529,8 +541,8 @@ void bvhTileKernel(const RasterParams p)
                         }
                         waveLdsSync();
                         const uint64_t roundMask = __ballot(mine);
-                        for (int region = 0; region < 16; ++region) {
-                            const int strip = region >> 1, hf = region & 1;
+                        for (int region = 0; region < kBvhWaves * kHalves; ++region) {
+                            const int strip = region / kHalves, hf = region % kHalves;
                             const int RX0 = (int)tileX0 + 32 * hf, RY0 = (int)tileY0 + 8 * strip;
                             uint64_t act = __ballot(mine && ix0 <= RX0 + 31 && ix0 + bw > RX0 &&
                                                     iy0 <= RY0 + 7 && iy0 + bh > RY0);
@@ -557,7 +569,7 @@ void bvhTileKernel(const RasterParams p)
                                     pixelTestKey(q, r01, r2d, (float)(RX0 + 4 * lx + b), invNear, lowv,
                                                  best[b], low[b]);
                             }
-                            unsigned long long *zrow = zbuf + (8 * strip + ly) * 64 + 32 * hf + 4 * lx;
+                            unsigned long long *zrow = zbuf + (8 * strip + ly) * TW + 32 * hf + 4 * lx;
 #pragma unroll
                             for (int b = 0; b < kRegionBlocks; ++b)
                                 if (low[b] != kNoHit)
@@ -600,7 +612,7 @@ void bvhTileKernel(const RasterParams p)
                     const int by0 = (int)((box >> 16) & 255u), by1 = by0 + (int)(box >> 24);
                     const bool rows = ent < listed && by0 <= 8 * wave + 7 && by1 >= 8 * wave;
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
+                    for (int hf = 0; hf < kHalves; ++hf) {
                         uint64_t act = __ballot(rows && bx0 <= 32 * hf + 31 && bx1 >= 32 * hf);
                         if (act == 0)
                             continue;
@@ -624,7 +636,7 @@ void bvhTileKernel(const RasterParams p)
                                 pixelTestKey(q, r01, r2d, (float)(tileX0 + 32 * hf + 4 * lx + b), invNear, lowv,
                                              best[b], low[b]);
                         }
-                        unsigned long long *zrow = zbuf + (8 * wave + ly) * 64 + 32 * hf + 4 * lx;
+                        unsigned long long *zrow = zbuf + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
 #pragma unroll
                         for (int b = 0; b < kRegionBlocks; ++b)
                             if (low[b] != kNoHit)
@@ -641,10 +653,10 @@ void bvhTileKernel(const RasterParams p)
             if (threadIdx.x == 0)
                 ctrl[0] = ctrl[2] = 0u;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
+            for (int hf = 0; hf < kHalves; ++hf)
 #pragma unroll
                 for (int b = 0; b < kRegionBlocks; ++b) {
-                    const unsigned long long z = zbuf[(8 * wave + ly) * 64 + 32 * hf + 4 * lx + b];
+                    const unsigned long long z = zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b];
                     const uint32_t low = (uint32_t)z;
                     const uint32_t slot = low & ((1u << kSlotBits) - 1u);
                     const uint32_t k = ~(low >> kSlotBits) & kKeyMask;
@@ -674,16 +686,16 @@ void bvhTileKernel(const RasterParams p)
     if (p.debugSkip & 1u)
         return;
     const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
-    const bool full = (p.nfast & 3u) == 0 && tileX0 + 64u <= p.nfast && tileY0 + 64u <= p.nslow;
+    const bool full = (p.nfast & 3u) == 0 && tileX0 + TW <= p.nfast && tileY0 + TH <= p.nslow;
     const uint32_t fy = tileY0 + 8u * wave + ly;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < kHalves; ++hf) {
         const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
         const size_t o = tileBase + (size_t)(8u * wave + ly) * p.nfast + hf * 32 + 4 * lx;
         uint32_t dep[kRegionBlocks], id[kRegionBlocks];
 #pragma unroll
         for (int b = 0; b < kRegionBlocks; ++b) {
-            const unsigned long long z = zbuf[(8 * wave + ly) * 64 + 32 * hf + 4 * lx + b];
+            const unsigned long long z = zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b];
             const uint32_t low = (uint32_t)z;
             dep[b] = low != 0u ? __float_as_uint(__builtin_amdgcn_rcpf(__uint_as_float((uint32_t)(z >> 32)))) : 0u;
             id[b] = IDS == 2 ? (uint32_t)seg[hf][b]
@@ -711,41 +723,55 @@ void bvhTileKernel(const RasterParams p)
 
 }  // namespace
 
-size_t bvhLdsBytes(uint32_t passInst, bool textured)
+namespace {
+// LDS bytes of one workgroup for a tile shape
+size_t ldsFor(uint32_t passInst, bool textured, int tw, int th)
 {
-    const size_t cap = textured ? tabCap<true>() : tabCap<false>();
-    return 4096 * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 16 + (size_t)kBigCap * 64 +
-           (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + sizeof(WaveScratch) * kBvhWaves;
+    const size_t cap = (size_t)tabCap(textured, tw, th);
+    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 16 + (size_t)bigCap(tw, th) * 64 +
+           (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + sizeof(WaveScratch) * (size_t)(th / 8);
 }
+}  // namespace
+
+size_t bvhLdsBytes(uint32_t passInst, bool textured) { return ldsFor(passInst, textured, 64, 64); }
 
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
 {
-    const uint32_t items = p.numViews * p.tilesFast * p.tilesSlow;
-    if (items == 0)
+    if (p.numViews == 0)
         return hipSuccess;
     const int ids = p.ids == nullptr ? 0 : p.idsAreSegmask ? 2 : 1;
     const bool tex = p.anyTextured != 0;
-    const size_t lds = bvhLdsBytes(p.bvhPassInst, tex);
-    const dim3 grid(items), block(kWave * kBvhWaves);
-#define MRX_BVH(I, T)                                                                          \
+    // tile shape: p.bvhTile = 0 (64x64), 1 (64x32: TW 64, TH 32), 2 (32x32)
+    const int tw = p.bvhTile == 2 ? 32 : 64, th = p.bvhTile == 0 ? 64 : 32;
+    const uint32_t items = p.numViews * ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
+    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th);
+    const dim3 grid(items), block(kWave * (th / 8));
+#define MRX_BVH(I, T, W, H)                                                                    \
     do {                                                                                       \
         static size_t allowed = 0;                                                             \
         if (lds > allowed) {                                                                   \
-            const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T>,        \
+            const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H>,  \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess)                                                               \
                 return e;                                                                      \
             allowed = lds;                                                                     \
         }                                                                                      \
-        bvhTileKernel<I, T><<<grid, block, lds, stream>>>(p);                                  \
+        bvhTileKernel<I, T, W, H><<<grid, block, lds, stream>>>(p);                            \
+    } while (0)
+#define MRX_BVH_SHAPE(I, T)                                                                    \
+    do {                                                                                       \
+        if (p.bvhTile == 0) MRX_BVH(I, T, 64, 64);                                             \
+        else if (p.bvhTile == 1) MRX_BVH(I, T, 64, 32);                                        \
+        else MRX_BVH(I, T, 32, 32);                                                            \
     } while (0)
     if (ids == 2) {
-        if (tex) MRX_BVH(2, true); else MRX_BVH(2, false);
+        if (tex) MRX_BVH_SHAPE(2, true); else MRX_BVH_SHAPE(2, false);
     } else if (ids == 1) {
-        if (tex) MRX_BVH(1, true); else MRX_BVH(1, false);
+        if (tex) MRX_BVH_SHAPE(1, true); else MRX_BVH_SHAPE(1, false);
     } else {
-        if (tex) MRX_BVH(0, true); else MRX_BVH(0, false);
+        if (tex) MRX_BVH_SHAPE(0, true); else MRX_BVH_SHAPE(0, false);
     }
+#undef MRX_BVH_SHAPE
 #undef MRX_BVH
     return hipGetLastError();
 }

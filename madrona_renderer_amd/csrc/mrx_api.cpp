@@ -675,7 +675,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.debugStamps = nullptr;
     if (const char *dbg = std::getenv("MRX_DEBUG_STAMPS"))
         if (std::atoi(dbg) != 0) {
-            const size_t n = ((size_t)nviews * p.tilesFast * p.tilesSlow + 64) * 4 * 8;
+            // (x4: the BVH kernel's 32x32 tile shape launches four workgroups per 64x64 tile)
+            const size_t n = ((size_t)nviews * p.tilesFast * p.tilesSlow * 4 + 64) * 4 * 8;
             MRX_HIP(r.stamps.alloc(n));
             MRX_HIP(hipMemset(r.stamps.ptr, 0, n * sizeof(unsigned long long)));
             p.debugStamps = r.stamps.ptr;
@@ -721,6 +722,9 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // TLAS records of up to 128 instances stay in LDS at once (two workgroups
     // per CU); larger worlds take several passes
     p.bvhPassInst = std::min<uint32_t>(128u, std::max<uint32_t>(64u, (maxWorldInst + 63u) / 64u * 64u));
+    p.bvhTile = 0;
+    if (const char *dbg = std::getenv("MRX_BVH_TILE"))
+        p.bvhTile = std::max(0, std::min(2, std::atoi(dbg)));
     p.bvhSmallArea = 32;
     if (const char *dbg = std::getenv("MRX_BVH_SMALL_AREA"))
         p.bvhSmallArea = std::max(0, std::min(4096, std::atoi(dbg)));

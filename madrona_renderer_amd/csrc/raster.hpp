@@ -130,6 +130,7 @@ struct RasterParams {
     const uint32_t *viewWorld;       // [views]
     const uint32_t *instKBase;       // [I]
     uint32_t bvhPassInst;            // instances whose TLAS records fit LDS at once (multiple of 64)
+    int32_t bvhTile;                 // tile of a workgroup: 0 = 64x64, 1 = 64 wide x 32, 2 = 32x32 (MRX_BVH_TILE)
     int32_t bvhSmallArea;            // boxes of up to this many pixels are walked by their triangle's lane
 };
 

@@ -271,3 +271,22 @@ def test_bench_shape_1024_worlds_482_triangles(native):
     got = fetch(r, visibility=False)
     ref = render_oracle(d, want_ids=False)
     assert_parity(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [1, 2], ids=["64x32", "32x32"])
+@pytest.mark.parametrize("case", ["cubes", "meshes-rt", "ragged-textured", "baseline-c3"])
+def test_tile_shapes_of_the_lds_depth_buffer_give_the_same_bytes(native, monkeypatch, tile, case):
+    # BASELINE configs[2] asks for an LDS tile-size sweep (64x64 / 64x32 / 32x32): the
+    # tile of the BVH kernel is a template parameter; every shape must render the
+    # oracle's image
+    monkeypatch.setenv("MRX_BVH_TILE", str(tile))
+    if case == "cubes":
+        d = meshes.cube_field(num_worlds=6, cubes=130, width=96, height=64, textured=True)
+    elif case == "meshes-rt":
+        d = _mesh_world("Raytracer", 128, 128)
+    elif case == "ragged-textured":
+        d = scenes.synthetic_scene(5, width=50, height=94, with_wall=True, textured=True)
+    else:
+        d = scenes.synthetic_scene(12, width=128, height=128, with_wall=True)
+    _parity(d, variant=BVH)
