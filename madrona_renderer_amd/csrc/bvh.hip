@@ -182,8 +182,8 @@ void bvhTileKernel(const RasterParams p)
     unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [TH][TW]
     float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + TW * TH);                         // [kCap] rgba tex obj k
     float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [4]
-    float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 4);                   // [kBigCap] planes, key, box
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [8]
+    float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 8);                   // [kBigCap] planes, key, box
     float *instRec = reinterpret_cast<float *>(bigList + kBigCap);                      // [passInst][24]
     float4 *instRect = reinterpret_cast<float4 *>(instRec + (size_t)passInst * kInstRecDw);
     WaveScratch *ws = reinterpret_cast<WaveScratch *>(instRect + passInst) + wave;
@@ -222,7 +222,8 @@ void bvhTileKernel(const RasterParams p)
     for (int i = threadIdx.x; i < TW * TH; i += kWave * kBvhWaves)
         zbuf[i] = packHit(invFar, 0u);
     if (threadIdx.x == 0)
-        ctrl[0] = ctrl[1] = ctrl[2] = 0u;          // records, waves that are done, large triangles
+        ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // records / done waves / large triangles;
+                                                                  // [4], [6]: records / large triangles of odd rounds
 
     // the lane's pixels at output time: strip = wave, four consecutive pixels of
     // one row in each 32-pixel half (one 16-byte store per tensor and half)
@@ -241,7 +242,7 @@ void bvhTileKernel(const RasterParams p)
         const uint32_t n = min(passInst, i1 - passBase);
         __syncthreads();                              // depth buffer initialised / previous TLAS consumed
         if (threadIdx.x == 0)
-            ctrl[1] = 0u;                             // (every wave has read the last pass's count by now)
+            ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // (every wave has read the last pass's counts by now)
         // ---- phase I: the TLAS of this pass, in LDS.  Lane = (instance, corner of
         //      its object's box): transform (S2/S3) and S6b quantities per
         //      instance, one projected corner per lane, 8-lane reduction.
@@ -304,7 +305,10 @@ void bvhTileKernel(const RasterParams p)
         float sMV[3][3] = {}, sTv[3] = {};
         bool done = (p.debugSkip & 4u) != 0;          // timing aid: no traversal at all
         bool reported = false;
-        for (;;) {
+        // the record and large-triangle counters alternate between two sets from
+        // round to round, so the idle set can be cleared while the other is read
+        uint32_t par = 0;
+        for (;; par ^= 4u) {
             // -- produce until this wave's share is exhausted or the record table is full
             bool tableFull = false;
             while (!tableFull) {
@@ -434,7 +438,7 @@ void bvhTileKernel(const RasterParams p)
                 const uint32_t numLive = (uint32_t)__builtin_popcountll(liveMask);
                 uint32_t slotBase = 0;
                 if (lane == 0 && numLive)
-                    slotBase = atomicAdd(&ctrl[0], numLive);
+                    slotBase = atomicAdd(&ctrl[0 + par], numLive);
                 slotBase = rflu(slotBase);
                 if (slotBase + numLive > (uint32_t)kCap) {
                     tableFull = true;                 // wait for the resolve, then take the batch again
@@ -508,7 +512,7 @@ void bvhTileKernel(const RasterParams p)
                     if (numBig) {
                         uint32_t bigBase = 0;
                         if (lane == 0)
-                            bigBase = atomicAdd(&ctrl[2], (uint32_t)numBig);
+                            bigBase = atomicAdd(&ctrl[2 + par], (uint32_t)numBig);
                         bigBase = rflu(bigBase);
                         if (bigBase + (uint32_t)numBig <= (uint32_t)kBigCap) {
                             if ((bigMask >> lane) & 1ull) {
@@ -602,9 +606,15 @@ void bvhTileKernel(const RasterParams p)
             __syncthreads();
             if (!(p.debugSkip & 128u)) MRX_STAMP(3);
             // -- the round's large triangles: wave = strip, lane = entry for the box
-            //    test, then four pixels of the lane per 32-pixel half
+            //    test, then four pixels of the lane per 32-pixel half.  From here to the
+            //    end of the round a wave touches only the pixels of its own strip (the
+            //    small-triangle walks ended at the barrier), so no barrier separates this
+            //    pass from the resolve below.
+            const bool allDone = rflu(ctrl[1]) == (uint32_t)kBvhWaves;
+            if (threadIdx.x == 0)
+                ctrl[0 + (par ^ 4u)] = ctrl[2 + (par ^ 4u)] = 0u;     // the next round's counters
             {
-                const uint32_t listed = min(rflu(ctrl[2]), (uint32_t)kBigCap);
+                const uint32_t listed = min(rflu(ctrl[2 + par]), (uint32_t)kBigCap);
                 for (uint32_t e0 = 0; e0 < listed; e0 += kWave) {
                     const uint32_t ent = e0 + (uint32_t)lane;
                     const uint32_t box = ent < listed ? __float_as_uint(bigList[ent][13]) : 0u;
@@ -645,13 +655,9 @@ void bvhTileKernel(const RasterParams p)
                 }
             }
             if (!(p.debugSkip & 128u)) MRX_STAMP(4);
-            __syncthreads();
             // -- resolve: every lane looks its eight pixels up; winners whose record
             //    is in the table of this round are shaded now (a later round reuses
             //    the table)
-            const bool allDone = rflu(ctrl[1]) == (uint32_t)kBvhWaves;
-            if (threadIdx.x == 0)
-                ctrl[0] = ctrl[2] = 0u;
 #pragma unroll
             for (int hf = 0; hf < kHalves; ++hf)
 #pragma unroll
@@ -728,7 +734,7 @@ namespace {
 size_t ldsFor(uint32_t passInst, bool textured, int tw, int th)
 {
     const size_t cap = (size_t)tabCap(textured, tw, th);
-    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 16 + (size_t)bigCap(tw, th) * 64 +
+    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 32 + (size_t)bigCap(tw, th) * 64 +
            (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + sizeof(WaveScratch) * (size_t)(th / 8);
 }
 }  // namespace
