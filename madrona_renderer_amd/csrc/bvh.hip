@@ -243,26 +243,45 @@ void bvhTileKernel(const RasterParams p)
         __syncthreads();                              // depth buffer initialised / previous TLAS consumed
         if (threadIdx.x == 0)
             ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // (every wave has read the last pass's counts by now)
-        // ---- phase I: the TLAS of this pass, in LDS.  Lane = (instance, corner of
-        //      its object's box): transform (S2/S3) and S6b quantities per
-        //      instance, one projected corner per lane, 8-lane reduction.
+        // ---- phase I: the TLAS of this pass, in LDS.
+        //      (a) lane = instance: transform (S2/S3) and S6b quantities, once per instance;
+        for (uint32_t ch = (uint32_t)wave; ch * kWave < n; ch += kBvhWaves) {
+            const uint32_t li = ch * kWave + (uint32_t)lane;
+            if (li < n) {
+                const uint32_t row = passBase + li;
+                // the object's range, root and box were copied per instance at load: no
+                // load depends on another here (an instance whose object id is negative
+                // this step is hidden)
+                const int32_t obj = p.instObj[row];
+                const float4 o0 = *reinterpret_cast<const float4 *>(p.instInfo + row);
+                InstXform x;
+                instanceTransform(p, vc, row, x);
+                float4 *dst = reinterpret_cast<float4 *>(instRec + (size_t)li * kInstRecDw);
+                dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
+                dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
+                dst[2] = make_float4(x.MV[2][2], x.tv[0], x.tv[1], x.tv[2]);
+                dst[3] = make_float4(x.qo[0], x.qo[1], x.qo[2], x.det);
+                dst[4] = make_float4(x.sc[0], x.sc[1], x.sc[2], __int_as_float(obj));
+                dst[5] = make_float4(__uint_as_float(p.instKBase[row]), o0.x, o0.y, o0.z);
+            }
+        }
+        __syncthreads();
+        //      (b) lane = (instance, corner of its object's box): one projected corner per
+        //          lane, 8-lane reduction -> the instance's padded screen rectangle.
         for (uint32_t base = (uint32_t)wave * 8u; base < n; base += kBvhWaves * 8u) {
             const uint32_t li = base + (uint32_t)(lane >> 3);
             const int corner = lane & 7;
             const bool has = li < n;
-            const uint32_t row = passBase + (has ? li : 0u);
-            // the object's range, root and box were copied per instance at load: no
-            // load depends on another here (an instance whose object id is negative
-            // this step is hidden)
-            const int32_t obj = p.instObj[row];
-            const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + row);
-            const float4 o0 = oi[0], omin = oi[1], omax = oi[2];
-            const bool okObj = has && obj >= 0;
-            InstXform x;
-            instanceTransform(p, vc, row, x);
+            const uint32_t lis = has ? li : 0u;
+            const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)lis * kInstRecDw);
+            const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a4 = rec[4], a5 = rec[5];
+            const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + passBase + lis);
+            const float4 omin = oi[1], omax = oi[2];
+            const float MV[3][3] = { { a0.x, a0.y, a0.z }, { a0.w, a1.x, a1.y }, { a1.z, a1.w, a2.x } };
+            const float tv[3] = { a2.y, a2.z, a2.w };
             float fx, fz;
             bool f;
-            projectCorner(p, x.MV, x.tv, (corner & 1) ? omax.x : omin.x, (corner & 2) ? omax.y : omin.y,
+            projectCorner(p, MV, tv, (corner & 1) ? omax.x : omin.x, (corner & 2) ? omax.y : omin.y,
                           (corner & 4) ? omax.z : omin.z, isx, isz, fx, fz, f);
             float x0 = fx, x1 = fx, z0 = fz, z1 = fz;
             int fr = f ? 1 : 0;
@@ -275,21 +294,14 @@ void bvhTileKernel(const RasterParams p)
                 fr &= __shfl_xor(fr, m);
             }
             Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
-            const uint32_t numTris = __float_as_uint(o0.y);
+            const bool okObj = has && __float_as_int(a4.w) >= 0;
+            const uint32_t numTris = __float_as_uint(a5.z);
             if (!okObj || numTris == 0u) {            // nothing to draw: a rectangle nothing meets
                 r.x0 = r.y0 = __builtin_inff();
                 r.x1 = r.y1 = -__builtin_inff();
             }
-            if (has && corner == 0) {
-                float4 *dst = reinterpret_cast<float4 *>(instRec + (size_t)li * kInstRecDw);
-                dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
-                dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
-                dst[2] = make_float4(x.MV[2][2], x.tv[0], x.tv[1], x.tv[2]);
-                dst[3] = make_float4(x.qo[0], x.qo[1], x.qo[2], x.det);
-                dst[4] = make_float4(x.sc[0], x.sc[1], x.sc[2], __int_as_float(obj));
-                dst[5] = make_float4(__uint_as_float(p.instKBase[row]), o0.x, o0.y, o0.z);
+            if (has && corner == 0)
                 instRect[li] = make_float4(r.x0, r.x1, r.y0, r.y1);
-            }
         }
         __syncthreads();
         MRX_STAMP(1);
@@ -467,36 +479,62 @@ void bvhTileKernel(const RasterParams p)
                 const bool small = live && area <= smallArea;
                 const bool big = live && !small;
                 if (!(p.debugSkip & 2u)) {
-                    // -- small triangles: the lane walks its triangle's box, four pixels
-                    //    of a row per step (independent packed FMAs)
+                    // -- small triangles, by (triangle, row of its box): the rows of all the
+                    //    batch's small triangles are numbered through (prefix sum over the
+                    //    lanes) and dealt 64 at a time, a lane fetches the planes of its row's
+                    //    triangle from the lane that set it up (ds_bpermute) and walks the row
+                    //    four pixels per step -- every lane has a row, however uneven the boxes
                     {
-                        const f32x2 A01 = { c.A0, c.A1 }, A2D = { c.A2, c.Dx };
-                        const f32x2 B01 = { c.B0, c.B1 }, B2D = { c.B2, c.Dy };
-                        const f32x2 C01 = { c.C0, c.C1 }, C2D = { c.C2, c.Dc };
-                        const int segs = (bw + 3) >> 2, xEnd = ix0 + bw;
-                        const int cnt = (small && !(p.debugSkip & 32u)) ? bh * segs : 0;
-                        int sx = ix0, sy = iy0;
-                        for (int i = 0; __ballot(i < cnt) != 0; ++i) {
-                            if (i < cnt) {
-                                const float py = (float)sy;
-                                const f32x2 yy = { py, py };
-                                const f32x2 r01 = fma2(B01, yy, C01);
-                                const f32x2 r2d = fma2(B2D, yy, C2D);
-                                unsigned long long *zrow = zbuf + (sy - (int)tileY0) * TW + (sx - (int)tileX0);
+                        const int rowsMine = (small && !(p.debugSkip & 32u)) ? bh : 0;
+                        int incl = rowsMine;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const float px = (float)(sx + j);
-                                    const f32x2 pp = { px, px };
-                                    const f32x2 e01 = fma2(A01, pp, r01);
-                                    const f32x2 e2d = fma2(A2D, pp, r2d);
-                                    if (sx + j < xEnd && fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f &&
-                                        e2d.y > invFar && e2d.y <= invNear)
-                                        atomicMax(zrow + j, packHit(e2d.y, lowKey));
-                                }
-                                sx += 4;
-                                if (sx >= xEnd) {
-                                    sx = ix0;
-                                    ++sy;
+                        for (int d = 1; d < kWave; d <<= 1) {
+                            const int t = __shfl_up(incl, d);
+                            incl += lane >= d ? t : 0;
+                        }
+                        const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+                        const int packedBox = ix0 | (bw << 16);        // (both < 2^15)
+                        for (int item0 = 0; item0 < total; item0 += kWave) {
+                            const int j = item0 + lane;
+                            const bool act = j < total;
+                            // the lane t whose rows hold item j: smallest t with incl[t] > j
+                            int t = 0;
+#pragma unroll
+                            for (int step = kWave / 2; step >= 1; step >>= 1) {
+                                const int probe = __builtin_amdgcn_ds_bpermute((t + step - 1) << 2, incl);
+                                t += probe <= j ? step : 0;
+                            }
+                            t = act ? t : 0;
+                            const int src = t << 2;
+                            const int inclT = __builtin_amdgcn_ds_bpermute(src, incl);
+                            const int rowsT = __builtin_amdgcn_ds_bpermute(src, rowsMine);
+                            const int boxT = __builtin_amdgcn_ds_bpermute(src, packedBox);
+                            const int y0T = __builtin_amdgcn_ds_bpermute(src, iy0);
+                            const uint32_t lowT = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lowKey);
+#define MRX_GATHER(v) __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v)))
+                            const f32x2 A01 = { MRX_GATHER(c.A0), MRX_GATHER(c.A1) }, A2D = { MRX_GATHER(c.A2), MRX_GATHER(c.Dx) };
+                            const f32x2 B01 = { MRX_GATHER(c.B0), MRX_GATHER(c.B1) }, B2D = { MRX_GATHER(c.B2), MRX_GATHER(c.Dy) };
+                            const f32x2 C01 = { MRX_GATHER(c.C0), MRX_GATHER(c.C1) }, C2D = { MRX_GATHER(c.C2), MRX_GATHER(c.Dc) };
+#undef MRX_GATHER
+                            const int xBeg = boxT & 0xFFFF, xEnd = xBeg + (boxT >> 16);
+                            const int sy = y0T + (j - (inclT - rowsT));
+                            const float py = (float)sy;
+                            const f32x2 yy = { py, py };
+                            const f32x2 r01 = fma2(B01, yy, C01);
+                            const f32x2 r2d = fma2(B2D, yy, C2D);
+                            unsigned long long *zline = zbuf + (sy - (int)tileY0) * TW - (int)tileX0;
+                            for (int sx = xBeg; __ballot(act && sx < xEnd) != 0; sx += 4) {
+                                if (act && sx < xEnd) {
+#pragma unroll
+                                    for (int q4 = 0; q4 < 4; ++q4) {
+                                        const float px = (float)(sx + q4);
+                                        const f32x2 pp = { px, px };
+                                        const f32x2 e01 = fma2(A01, pp, r01);
+                                        const f32x2 e2d = fma2(A2D, pp, r2d);
+                                        if (sx + q4 < xEnd && fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f &&
+                                            e2d.y > invFar && e2d.y <= invNear)
+                                            atomicMax(zline + sx + q4, packHit(e2d.y, lowT));
+                                    }
                                 }
                             }
                         }
