@@ -184,6 +184,10 @@ struct mrx_renderer {
     DevBuf<float> depth;
     DevBuf<int32_t> ids;
     DevBuf<unsigned long long> stamps;
+    // XCD phase feedback (raster.hip): a host-mapped word workgroup 0 reports its XCC id to
+    uint32_t *xccHost = nullptr, *xccDev = nullptr;
+    int32_t xcdPhaseForced = -1;                // MRX_XCD_PHASE: 0 / 1 override (tests)
+    uint32_t launches = 0;
     // BVH path: BLAS (built at load) and the tables the per-step TLAS reads
     DevBuf<mrx::BvhNode> bvhNodes;
     DevBuf<uint32_t> bvhLeafTris, worldInstStart, viewWorld, instKBase;
@@ -193,6 +197,16 @@ struct mrx_renderer {
 
     hipError_t launch()
     {
+        // the parity workgroup 0 reported some launches ago (the word is written by the
+        // device without synchronisation: any value it ever held is a valid prediction)
+        if (xcdPhaseForced >= 0)
+            params.xcdPhase = (uint32_t)xcdPhaseForced;
+        else if (xccHost)
+            params.xcdPhase = *(volatile uint32_t *)xccHost & 1u;
+        // (the report is a write over PCIe: asked for in the first launches and then in
+        // every 32nd -- the phase of a queue changes rarely)
+        ++launches;
+        params.xccReport = (xccDev && (launches <= 4 || (launches & 31u) == 0)) ? xccDev : nullptr;
         if (useBvh)
             return mrx::launchBvh(params, stream);
         return mrx::launchRaster(params, info.max_world_triangles, variant, stream);
@@ -206,6 +220,7 @@ struct mrx_renderer {
         instPos.release(); instRot.release(); instScale.release();
         camPos.release(); camRot.release(); instObj.release();
         rgb.release(); depth.release(); ids.release(); stamps.release();
+        if (xccHost) (void)hipHostFree(xccHost);
         bvhNodes.release(); bvhLeafTris.release(); worldInstStart.release();
         viewWorld.release(); instKBase.release(); objInfo.release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -694,6 +709,18 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.xcdRotateWanted = -1;
     if (const char *dbg = std::getenv("MRX_XCD_ROTATE"))
         p.xcdRotateWanted = std::atoi(dbg);
+    p.xccReport = nullptr;
+    p.xcdPhase = 0;
+    if (hipHostMalloc((void **)&r.xccHost, 64, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer((void **)&r.xccDev, r.xccHost, 0) == hipSuccess) {
+        *r.xccHost = 0;
+        p.xccReport = r.xccDev;
+    } else {
+        (void)hipGetLastError();                  // no feedback: the split assumes an even start
+        r.xccHost = nullptr;
+    }
+    if (const char *dbg = std::getenv("MRX_XCD_PHASE"))
+        r.xcdPhaseForced = std::atoi(dbg) & 1;
     p.xcdSkew = 0;
     p.xcdSkewWanted = -1;
     if (const char *dbg = std::getenv("MRX_XCD_SKEW"))
@@ -769,27 +796,29 @@ int mrx_device_count(void)
     return n;
 }
 
-// Where LARGE output tensors land in HBM matters on some boxes: with tensors of
-// 256 MiB and more the same launch streams its stores ~20 % faster into some
+// Where the output tensors land in HBM matters: the same launch streams its
+// stores 5 - 7 % (128 MiB of output) to ~20 % (0.5 - 3 GiB) faster into some
 // allocations than into others, steadily for the life of the allocation
-// (profiles/r02_placement.txt).  Nothing visible from user space
-// predicts which -- not the layout, not the distance between the tensors, not
-// the address; some boxes offer no fast allocation at all -- so for such
-// outputs a few candidates are allocated one after another (alternately all
-// tensors in one block and one block per tensor), each timed with a few
-// renders, and the fastest kept.  Bounded: at most two candidates (the best so
-// far and the current one) plus one small spacer are alive at any time, at most
-// four are tried, and nothing is tried when two more copies of the outputs
-// would not fit a quarter of the free memory.  Outputs below 256 MiB (every
-// 64x64 batch up to 8192 views) are laid out deterministically in one block --
-// depth at phase 256 KiB of the 512 KiB period -- and need no search: all their
-// candidates measured the same.  MRX_PLACEMENT_TRIES=1 switches the search off.
+// (profiles/r02_placement.txt).  In a fresh process the
+// one-block layout (depth at phase 256 KiB of the 512 KiB period) is reliably
+// fast for outputs below 256 MiB; in a process with an allocation history it is
+// not (the headline batch read 24.9 instead of 22.5 us after a test session had
+// allocated and freed gigabytes), and for 256 MiB+ tensors nothing visible from
+// user space predicts the fast mode -- not the layout, not the distance between
+// the tensors, not the address; some boxes offer none.  So a few candidates are
+// allocated one after another (alternately all tensors in one block and one
+// block per tensor), each timed with a few renders, and the fastest kept.
+// Bounded: at most two candidates (the best so far and the current one) plus
+// one small spacer are alive at any time, at most four are tried, outputs below
+// 32 MiB are not searched, and nothing is tried when two more copies of the
+// outputs would not fit a quarter of the free memory.
+// MRX_PLACEMENT_TRIES=1 switches the search off.
 static int choosePlacement(mrx_renderer *r)
 {
     const size_t px = r->rgb.count;
     const bool wantIds = r->ids.ptr != nullptr;
     const size_t bytes = px * 4 * (wantIds ? 3 : 2);
-    int maxTries = (bytes >= (256ull << 20) && bytes <= (16ull << 30)) ? 4 : 1;
+    int maxTries = (bytes >= (32ull << 20) && bytes <= (16ull << 30)) ? 4 : 1;
     if (const char *dbg = std::getenv("MRX_PLACEMENT_TRIES"))
         maxTries = std::max(1, std::min(16, std::atoi(dbg)));
     if (maxTries > 1) {
@@ -876,8 +905,9 @@ static int choosePlacement(mrx_renderer *r)
         } else {
             freeCand(c);
         }
-        // the two modes lie ~20 % apart, candidates of one mode scatter by +-4 %
-        if (best.us <= 0.88f * tmax)
+        // the two modes lie 5 - 7 % (outputs below 256 MiB) to ~20 % apart; candidates of
+        // one mode scatter by +-0.5 % (small) to +-4 % (large)
+        if (best.us <= (bytes < (256ull << 20) ? 0.965f : 0.88f) * tmax)
             break;                                    // a fast placement
     }
     if (trace)

@@ -658,7 +658,21 @@ void rasterGroupKernel(const RasterParams p)
     // two places on within its round of eight, round after round, so that an
     // XCD does not keep writing the same eighth of every 512 KiB of the output
     // (parity is kept: the XCD-aware split below pairs even with odd groups).
-    uint32_t bid = blockIdx.x;
+    // Which XCD a launch's workgroup 0 lands on depends on the hardware queue and what
+    // ran on it before (measured: XCC 0, 6 or 7 for different streams of one process,
+    // stable from launch to launch; profiles/r02_xcd_phase.txt).  On an odd start the
+    // XCD-aware split below would move its strips the wrong way (24.9 instead of 22.5
+    // us), so the two workgroups of every pair trade places then: p.xcdPhase is the
+    // parity workgroup 0 reported in an earlier launch of this renderer (a kernel
+    // argument -- every workgroup sees the same value, so the trade is consistent
+    // whatever the hardware does; a stale value costs speed, never pixels).
+    const uint32_t blk = (SLOTS == 16 && p.xcdSkew && (blockIdx.x ^ 1u) < gridDim.x)
+                             ? blockIdx.x ^ (p.xcdPhase & 1u) : blockIdx.x;
+    // workgroup 0 reports where it runs: a host-mapped word, written by the last wave,
+    // which issues no loads during set-up -- the slow write sits ahead of nothing
+    if (blockIdx.x == 0 && threadIdx.x == (groupWaves(TEX) - 1) * kWave && p.xccReport)
+        *p.xccReport = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
+    uint32_t bid = blk;
     if (p.xcdRotate && (bid | 7u) < gridDim.x)
         bid = (bid & ~7u) | ((bid + 2u * (bid >> 3)) & 7u);
     if (p.grpPerView == 1) {
@@ -673,13 +687,13 @@ void rasterGroupKernel(const RasterParams p)
         groupTiles = min(p.grpChunkTiles, tilesPerView - firstTile);
     }
     // XCD-aware split (see launchRaster; one-tile views, four per group):
-    // workgroup b runs on XCD b % 8 and the odd XCD of each pair drains its
-    // stores more slowly.  Workgroups 2m and 2m+1 share the view between their
-    // two runs of four: the odd one leaves its first p.xcdSkew strips to the
-    // even one (both set the view up).
+    // consecutive workgroups run on consecutive XCDs and the odd XCD of each pair
+    // drains its stores more slowly.  Workgroups 2m and 2m+1 (after the trade above:
+    // even = on an even XCD) share the view between their two runs of four: the odd
+    // one leaves its first p.xcdSkew strips to the even one (both set the view up).
     uint32_t firstStrip = 0, numStrips = groupTiles * 8;
     if (SLOTS == 16 && p.xcdSkew) {
-        if (blockIdx.x & 1u) {
+        if (blk & 1u) {
             firstStrip = p.xcdSkew;
             numStrips -= p.xcdSkew;
         } else {

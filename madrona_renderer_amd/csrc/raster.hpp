@@ -110,6 +110,11 @@ struct RasterParams {
     // MRX_XCD_SKEW override: -1 automatic, 0 off, 1..7 strips.
     uint32_t xcdSkew;
     int32_t xcdSkewWanted;
+    // XCD phase feedback of the split: workgroup 0 of every launch writes its XCC id to
+    // a host-mapped word; its parity, read back by the host before a later launch, makes
+    // the workgroups of each pair trade places (raster.hip)
+    uint32_t *xccReport;
+    uint32_t xcdPhase;
     // rotate the group <-> XCD relation by two every round of eight workgroups
     // (MRX_XCD_ROTATE override: -1 automatic, 0 off, 1 on)
     uint32_t xcdRotate;
