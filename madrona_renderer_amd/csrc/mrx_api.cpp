@@ -796,29 +796,29 @@ int mrx_device_count(void)
     return n;
 }
 
-// Where the output tensors land in HBM matters: the same launch streams its
-// stores 5 - 7 % (128 MiB of output) to ~20 % (0.5 - 3 GiB) faster into some
+// Where LARGE output tensors land in HBM matters on some boxes: with tensors of
+// 256 MiB and more the same launch streams its stores ~20 % faster into some
 // allocations than into others, steadily for the life of the allocation
-// (profiles/r02_placement.txt).  In a fresh process the
-// one-block layout (depth at phase 256 KiB of the 512 KiB period) is reliably
-// fast for outputs below 256 MiB; in a process with an allocation history it is
-// not (the headline batch read 24.9 instead of 22.5 us after a test session had
-// allocated and freed gigabytes), and for 256 MiB+ tensors nothing visible from
-// user space predicts the fast mode -- not the layout, not the distance between
-// the tensors, not the address; some boxes offer none.  So a few candidates are
-// allocated one after another (alternately all tensors in one block and one
-// block per tensor), each timed with a few renders, and the fastest kept.
-// Bounded: at most two candidates (the best so far and the current one) plus
-// one small spacer are alive at any time, at most four are tried, outputs below
-// 32 MiB are not searched, and nothing is tried when two more copies of the
-// outputs would not fit a quarter of the free memory.
+// (profiles/r02_placement.txt).  Nothing visible from user space
+// predicts which -- not the layout, not the distance between the tensors, not
+// the address, not the XCD phase of the queue; some boxes offer no fast
+// allocation at all -- so for such outputs a few candidates are allocated one
+// after another (alternately all tensors in one block and one block per
+// tensor), each timed with a few renders, and the fastest kept.  Bounded: at
+// most two candidates (the best so far and the current one) plus one small
+// spacer are alive at any time, at most four are tried, and nothing is tried
+// when two more copies of the outputs would not fit a quarter of the free
+// memory.  Outputs below 256 MiB (every 64x64 batch up to 8192 views) are laid
+// out deterministically in one block -- depth at phase 256 KiB of the 512 KiB
+// period -- and need no search (what looked like a placement lottery for them
+// in round 1 was the XCD phase of the stream: raster.hip, xcdPhase).
 // MRX_PLACEMENT_TRIES=1 switches the search off.
 static int choosePlacement(mrx_renderer *r)
 {
     const size_t px = r->rgb.count;
     const bool wantIds = r->ids.ptr != nullptr;
     const size_t bytes = px * 4 * (wantIds ? 3 : 2);
-    int maxTries = (bytes >= (32ull << 20) && bytes <= (16ull << 30)) ? 4 : 1;
+    int maxTries = (bytes >= (256ull << 20) && bytes <= (16ull << 30)) ? 4 : 1;
     if (const char *dbg = std::getenv("MRX_PLACEMENT_TRIES"))
         maxTries = std::max(1, std::min(16, std::atoi(dbg)));
     if (maxTries > 1) {
