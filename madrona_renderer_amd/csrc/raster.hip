@@ -638,7 +638,12 @@ __device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t 
 // textured variant (its texel loads cost registers and vmcnt drains).
 constexpr int groupWaves(bool tex) { return tex ? 4 : 8; }
 
-template <bool IDS, int SLOTS, bool TEX>
+// XMODE (16-slot instantiations only): bit 0 = the workgroups of every pair trade places
+// (XCD phase, below), bit 1 = workgroup 0 reports the XCD it runs on.  Separate
+// instantiations, chosen per launch by the host, because any extra state in this kernel's
+// work loop costs more than the split gains (59 of 64 VGPRs, SGPRs spilled): XMODE 0 is
+// the kernel as it always was.
+template <bool IDS, int SLOTS, bool TEX, int XMODE = 0>
 // (the second bound is waves per SIMD; 256-slot groups are LDS-limited to 3 per CU)
 __global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? (SLOTS > 128 ? 3 : 4) : (SLOTS > 128 ? 6 : 8))
 void rasterGroupKernel(const RasterParams p)
@@ -662,15 +667,15 @@ void rasterGroupKernel(const RasterParams p)
     // ran on it before (measured: XCC 0, 6 or 7 for different streams of one process,
     // stable from launch to launch; profiles/r02_xcd_phase.txt).  On an odd start the
     // XCD-aware split below would move its strips the wrong way (24.9 instead of 22.5
-    // us), so the two workgroups of every pair trade places then: p.xcdPhase is the
-    // parity workgroup 0 reported in an earlier launch of this renderer (a kernel
-    // argument -- every workgroup sees the same value, so the trade is consistent
-    // whatever the hardware does; a stale value costs speed, never pixels).
-    const uint32_t blk = (SLOTS == 16 && p.xcdSkew && (blockIdx.x ^ 1u) < gridDim.x)
-                             ? blockIdx.x ^ (p.xcdPhase & 1u) : blockIdx.x;
+    // us), so the two workgroups of every pair trade places then (XMODE bit 0): the host
+    // picks the instantiation by the parity workgroup 0 reported in an earlier launch
+    // of this renderer -- every workgroup of a launch runs the same code, so the trade
+    // is consistent whatever the hardware does; a stale value costs speed, never pixels.
+    const uint32_t blk = ((XMODE & 1) && SLOTS == 16 && p.xcdSkew && (blockIdx.x ^ 1u) < gridDim.x)
+                             ? blockIdx.x ^ 1u : blockIdx.x;
     // workgroup 0 reports where it runs: a host-mapped word, written by the last wave,
     // which issues no loads during set-up -- the slow write sits ahead of nothing
-    if (blockIdx.x == 0 && threadIdx.x == (groupWaves(TEX) - 1) * kWave && p.xccReport)
+    if ((XMODE & 2) && blockIdx.x == 0 && threadIdx.x == (groupWaves(TEX) - 1) * kWave && p.xccReport)
         *p.xccReport = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
     uint32_t bid = blk;
     if (p.xcdRotate && (bid | 7u) < gridDim.x)
@@ -1076,21 +1081,30 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
             q.xcdRotate = p.xcdRotateWanted ? 1u : 0u;
         const dim3 grid(numGroups);
         const dim3 gblock(kWave * groupWaves(p.anyTextured != 0));
-#define MRX_GROUP(S)                                                           \
+#define MRX_GROUP_X(S, X)                                                      \
     do {                                                                       \
         if (p.anyTextured) {                                                   \
-            if (ids) rasterGroupKernel<true, S, true><<<grid, gblock, 0, stream>>>(q);   \
-            else     rasterGroupKernel<false, S, true><<<grid, gblock, 0, stream>>>(q);  \
+            if (ids) rasterGroupKernel<true, S, true, X><<<grid, gblock, 0, stream>>>(q);   \
+            else     rasterGroupKernel<false, S, true, X><<<grid, gblock, 0, stream>>>(q);  \
         } else {                                                               \
-            if (ids) rasterGroupKernel<true, S, false><<<grid, gblock, 0, stream>>>(q);  \
-            else     rasterGroupKernel<false, S, false><<<grid, gblock, 0, stream>>>(q); \
+            if (ids) rasterGroupKernel<true, S, false, X><<<grid, gblock, 0, stream>>>(q);  \
+            else     rasterGroupKernel<false, S, false, X><<<grid, gblock, 0, stream>>>(q); \
         }                                                                      \
     } while (0)
-        if (slots == 16) MRX_GROUP(16);
+#define MRX_GROUP(S) MRX_GROUP_X(S, 0)
+        if (slots == 16) {
+            // XCD phase: trade places within the pairs on an odd start, ask for a report now and then
+            const int xmode = ((q.xcdSkew && (p.xcdPhase & 1u)) ? 1 : 0) | (p.xccReport ? 2 : 0);
+            if (xmode == 0) MRX_GROUP_X(16, 0);
+            else if (xmode == 1) MRX_GROUP_X(16, 1);
+            else if (xmode == 2) MRX_GROUP_X(16, 2);
+            else MRX_GROUP_X(16, 3);
+        }
         else if (slots == 32) MRX_GROUP(32);
         else if (slots == 64) MRX_GROUP(64);
         else if (slots == 128) MRX_GROUP(128);
         else MRX_GROUP(256);
+#undef MRX_GROUP_X
 #undef MRX_GROUP
     }
     return hipGetLastError();

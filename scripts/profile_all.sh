@@ -5,8 +5,10 @@
 # gpurun_out/<tag>_<config>/summary.json, plus the un-profiled bench line of each.
 set -eu
 R="${1:-r02}"
+ONLY="${2:-}"          # optional: space-separated list of configuration names to run
 run() {  # name, steps, bench args
   local name="$1" steps="$2"; shift 2
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return 0; fi
   echo "== $name: $*"
   STEPS="$steps" BENCH_ARGS="$*" bash "$GRAFT_REPO_ROOT/scripts/profile_round.sh" "${R}_${name}" > "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}.log" 2>&1 || tail -5 "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}.log"
   python3 "$GRAFT_REPO_ROOT/bench.py" --steps "$steps" --warmup 200 --no-extra --no-cpu-baseline "$@" > "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}/bench.json" 2>/dev/null || true
