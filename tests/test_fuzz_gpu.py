@@ -112,3 +112,25 @@ def test_random_scene_on_brute_variant_too(native):
     d = _scene(11, num_worlds=16, width=64, height=64, mode="Rasterizer")
     r = make_product(d, visibility=True, variant=1)
     assert_parity(fetch(r), render_oracle(d))
+
+
+@pytest.mark.parametrize("seed,size,mode,tile", [
+    (41, (64, 64), "Rasterizer", 0), (50, (96, 48), "Rasterizer", 0), (51, (37, 53), "Rasterizer", 1),
+    (44, (64, 64), "Raytracer", 0), (45, (100, 100), "Raytracer", 2), (52, (128, 64), "Rasterizer", 0),
+    (47, (64, 64), "Rasterizer", 2), (56, (200, 136), "Rasterizer", 0), (58, (64, 64), "Rasterizer", 1),
+    (63, (160, 160), "Raytracer", 0),
+])
+def test_random_raw_geometry_scenes_through_the_bvh_path(native, monkeypatch, seed, size, mode, tile):
+    # the same soup of triangles at every scale -- crossing the eye plane (unbounded screen
+    # rectangles), edge-on, sub-pixel, coincident (ties) -- forced through the BVH path: TLAS
+    # rectangles, the (triangle, row) walk of small boxes, the shared list of large ones and
+    # the LDS depth buffer must agree with the oracle bit for bit, for every tile shape
+    monkeypatch.setenv("MRX_BVH_TILE", str(tile))
+    if seed % 2:
+        monkeypatch.setenv("MRX_BVH_SMALL_AREA", str([0, 8, 200, 4096][seed % 4]))
+    d = _scene(seed, num_worlds=24, width=size[0], height=size[1], mode=mode)
+    r = make_product(d, visibility=True, variant=2)
+    got = fetch(r)
+    ref = render_oracle(d)
+    assert_parity(got, ref)
+    assert (ref["tri_id"] >= 0).mean() > 0.01
