@@ -38,6 +38,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "crossover":
         cases = [("1024 x 64^2, %d cubes (%d tris)" % (c, 12 * c + 2), meshes.cube_field(1024, c), 200)
                  for c in (2, 5, 10, 15, 21, 30, 40)]
+    if len(sys.argv) > 1 and sys.argv[1] == "bvhonly":
+        cases = cases[:4] + [("1024 x 64^2, 40 textured cubes", meshes.cube_field(1024, 40, textured=True), 200)]
+        for name, desc, steps in cases:
+            print("%-44s bvh %9.2f us" % (name, timed(desc, 2, steps)), flush=True)
+        return
     for name, desc, steps in cases:
         row = []
         for variant in (2, 3):
