@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-SETTLE_S = 0.25          # untimed renders before the warm-up (clocks leave idle only under load)
+# untimed renders before the warm-up (clocks leave idle only under load); reported as `settle_s`
+SETTLE_S = float(os.environ.get("MRX_BENCH_SETTLE_S", "0.25"))
 
 
 def parse():
