@@ -240,48 +240,44 @@ void bvhTileKernel(const RasterParams p)
 
     for (uint32_t passBase = i0; passBase < i1; passBase += passInst) {
         const uint32_t n = min(passInst, i1 - passBase);
-        __syncthreads();                              // depth buffer initialised / previous TLAS consumed
-        if (threadIdx.x == 0)
-            ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // (every wave has read the last pass's counts by now)
-        // ---- phase I: the TLAS of this pass, in LDS.
-        //      (a) lane = instance: transform (S2/S3) and S6b quantities, once per instance;
-        for (uint32_t ch = (uint32_t)wave; ch * kWave < n; ch += kBvhWaves) {
-            const uint32_t li = ch * kWave + (uint32_t)lane;
-            if (li < n) {
-                const uint32_t row = passBase + li;
-                // the object's range, root and box were copied per instance at load: no
-                // load depends on another here (an instance whose object id is negative
-                // this step is hidden)
-                const int32_t obj = p.instObj[row];
-                const float4 o0 = *reinterpret_cast<const float4 *>(p.instInfo + row);
-                InstXform x;
-                instanceTransform(p, vc, row, x);
+        if (passBase != i0) {
+            // (the first pass has nothing to wait for: the barrier that closes phase I also
+            // orders the clearing of the depth buffer above ahead of its first use)
+            __syncthreads();                          // previous TLAS consumed
+            if (threadIdx.x == 0)
+                ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // (every wave has read the last pass's counts by now)
+        }
+        // ---- phase I: the TLAS of this pass, in LDS.  Lane = (instance, corner of its
+        //      object's box).  The eight lanes of an instance all compute its transform
+        //      (S2/S3, the S6b quantities) -- redundant but free across a wave, and it
+        //      saves the barrier and the LDS round trip a lane-per-instance step ahead of
+        //      the projection would need; each then projects one corner, an 8-lane
+        //      reduction gives the instance's padded screen rectangle.  The object's
+        //      range, root and box were copied per instance at load: no load depends on
+        //      another here (an instance whose object id is negative this step is hidden).
+        for (uint32_t base = (uint32_t)wave * 8u; base < n; base += kBvhWaves * 8u) {
+            const uint32_t li = base + (uint32_t)(lane >> 3);
+            const int corner = lane & 7;
+            const bool has = li < n;
+            const uint32_t row = passBase + (has ? li : 0u);
+            const int32_t obj = p.instObj[row];
+            const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + row);
+            const float4 o0 = oi[0], omin = oi[1], omax = oi[2];
+            const uint32_t kBase = p.instKBase[row];
+            InstXform x;
+            instanceTransform(p, vc, row, x);
+            if (has && corner == 0) {
                 float4 *dst = reinterpret_cast<float4 *>(instRec + (size_t)li * kInstRecDw);
                 dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
                 dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
                 dst[2] = make_float4(x.MV[2][2], x.tv[0], x.tv[1], x.tv[2]);
                 dst[3] = make_float4(x.qo[0], x.qo[1], x.qo[2], x.det);
                 dst[4] = make_float4(x.sc[0], x.sc[1], x.sc[2], __int_as_float(obj));
-                dst[5] = make_float4(__uint_as_float(p.instKBase[row]), o0.x, o0.y, o0.z);
+                dst[5] = make_float4(__uint_as_float(kBase), o0.x, o0.y, o0.z);
             }
-        }
-        __syncthreads();
-        //      (b) lane = (instance, corner of its object's box): one projected corner per
-        //          lane, 8-lane reduction -> the instance's padded screen rectangle.
-        for (uint32_t base = (uint32_t)wave * 8u; base < n; base += kBvhWaves * 8u) {
-            const uint32_t li = base + (uint32_t)(lane >> 3);
-            const int corner = lane & 7;
-            const bool has = li < n;
-            const uint32_t lis = has ? li : 0u;
-            const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)lis * kInstRecDw);
-            const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a4 = rec[4], a5 = rec[5];
-            const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + passBase + lis);
-            const float4 omin = oi[1], omax = oi[2];
-            const float MV[3][3] = { { a0.x, a0.y, a0.z }, { a0.w, a1.x, a1.y }, { a1.z, a1.w, a2.x } };
-            const float tv[3] = { a2.y, a2.z, a2.w };
             float fx, fz;
             bool f;
-            projectCorner(p, MV, tv, (corner & 1) ? omax.x : omin.x, (corner & 2) ? omax.y : omin.y,
+            projectCorner(p, x.MV, x.tv, (corner & 1) ? omax.x : omin.x, (corner & 2) ? omax.y : omin.y,
                           (corner & 4) ? omax.z : omin.z, isx, isz, fx, fz, f);
             float x0 = fx, x1 = fx, z0 = fz, z1 = fz;
             int fr = f ? 1 : 0;
@@ -294,9 +290,8 @@ void bvhTileKernel(const RasterParams p)
                 fr &= __shfl_xor(fr, m);
             }
             Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
-            const bool okObj = has && __float_as_int(a4.w) >= 0;
-            const uint32_t numTris = __float_as_uint(a5.z);
-            if (!okObj || numTris == 0u) {            // nothing to draw: a rectangle nothing meets
+            const uint32_t numTris = __float_as_uint(o0.y);
+            if (!(has && obj >= 0) || numTris == 0u) {   // nothing to draw: a rectangle nothing meets
                 r.x0 = r.y0 = __builtin_inff();
                 r.x1 = r.y1 = -__builtin_inff();
             }
