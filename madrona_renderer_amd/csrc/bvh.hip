@@ -440,8 +440,11 @@ void bvhTileKernel(const RasterParams p)
                 uint32_t kTri = 0;
                 int32_t objL = -1;
                 float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
+                float4 texDesc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((uint32_t)lane < nb && !(p.debugSkip & 8u)) {
                     const uint2 e = ws->queue[lane];
+                    if (TEX)                          // the texture descriptor stored with the triangle's material
+                        texDesc = reinterpret_cast<const float4 *>(p.triMats + e.y)[3];
                     const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)e.x * kInstRecDw);
                     const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4], a5 = rec[5];
                     InstXform x;
@@ -475,6 +478,9 @@ void bvhTileKernel(const RasterParams p)
 #pragma unroll
                         for (int i = 0; i < 9; ++i)
                             coldTab[slot][i] = cold[i];
+                        coldTab[slot][9] = texDesc.x;
+                        coldTab[slot][10] = texDesc.y;
+                        coldTab[slot][11] = texDesc.z;
                     }
                 }
                 if (p.debugSkip & 128u) MRX_STAMP(3);
@@ -708,7 +714,13 @@ void bvhTileKernel(const RasterParams p)
             //    is in the table of this round are shaded now (a later round reuses
             //    the table)
 #pragma unroll
-            for (int hf = 0; hf < kHalves; ++hf)
+            for (int hf = 0; hf < kHalves; ++hf) {
+                // Textured winners: the texel loads of the half's four pixels are all
+                // issued before any is used (addresses of untextured pixels point at texel
+                // 0) -- under per-pixel branches every load waited for the one before it,
+                // 8 x (descriptor, texel) round trips per lane and round.
+                uint32_t texSlot[kRegionBlocks];
+                bool texOn[kRegionBlocks], anyTexOn = false;
 #pragma unroll
                 for (int b = 0; b < kRegionBlocks; ++b) {
                     const unsigned long long z = zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b];
@@ -716,17 +728,54 @@ void bvhTileKernel(const RasterParams p)
                     const uint32_t slot = low & ((1u << kSlotBits) - 1u);
                     const uint32_t k = ~(low >> kSlotBits) & kKeyMask;
                     const float4 rec = shadeTab[slot < (uint32_t)kCap ? slot : 0u];
-                    if (low != 0u && slot < (uint32_t)kCap && __float_as_uint(rec.w) == k) {
+                    const bool mine = low != 0u && slot < (uint32_t)kCap && __float_as_uint(rec.w) == k;
+                    if (mine) {
                         rgba[hf][b] = __float_as_uint(rec.x);
                         seg[hf][b] = __float_as_int(rec.z);
-                        const int32_t tex = __float_as_int(rec.y);
-                        if (TEX && tex >= 0)
-                            rgba[hf][b] = shadeTextured(p, coldTab[slot], tex,
-                                                        (float)(tileX0 + hf * 32 + 4 * lx + b),
-                                                        (float)(tileY0 + 8u * wave + ly),
-                                                        1.0f / __uint_as_float((uint32_t)(z >> 32)));
+                    }
+                    if (TEX) {
+                        texOn[b] = mine && __float_as_int(rec.y) >= 0;
+                        texSlot[b] = texOn[b] ? slot : 0u;
+                        anyTexOn = anyTexOn || texOn[b];
                     }
                 }
+                if (TEX && __ballot(anyTexOn) != 0) {
+                    uint32_t texAddr[kRegionBlocks], texel[kRegionBlocks];
+#pragma unroll
+                    for (int b = 0; b < kRegionBlocks; ++b) {
+                        const float *cold = coldTab[texSlot[b]];
+                        const float it = __uint_as_float((uint32_t)(zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b] >> 32));
+                        // S8, as shadeTextured() of raster_dev.hpp (same operations in the same order)
+                        const float px = (float)(tileX0 + hf * 32 + 4 * lx + b), py = (float)(tileY0 + 8u * wave + ly);
+                        const float tt = 1.0f / it;
+                        const float u = __builtin_fmaf(cold[0], px, __builtin_fmaf(cold[1], py, cold[2])) * tt;
+                        const float v = __builtin_fmaf(cold[3], px, __builtin_fmaf(cold[4], py, cold[5])) * tt;
+                        const int tw = __float_as_int(cold[10]), th = __float_as_int(cold[11]);
+                        const float uf = u - floorf(u);
+                        float vf = v - floorf(v);
+                        vf = 1.0f - vf;
+                        int tx = (int)(uf * (float)tw);
+                        int ty = (int)(vf * (float)th);
+                        tx = tx > tw - 1 ? tw - 1 : tx;
+                        ty = ty > th - 1 ? th - 1 : ty;
+                        tx = tx < 0 ? 0 : tx;
+                        ty = ty < 0 ? 0 : ty;
+                        texAddr[b] = texOn[b] ? __float_as_uint(cold[9]) + (uint32_t)ty * (uint32_t)tw + (uint32_t)tx : 0u;
+                    }
+#pragma unroll
+                    for (int b = 0; b < kRegionBlocks; ++b)
+                        texel[b] = p.texels[texAddr[b]];
+#pragma unroll
+                    for (int b = 0; b < kRegionBlocks; ++b)
+                        if (texOn[b]) {
+                            const float *cold = coldTab[texSlot[b]];
+                            const uint32_t r8 = toU8(((float)(texel[b] & 255u) * (1.0f / 255.0f)) * cold[6]);
+                            const uint32_t g8 = toU8(((float)((texel[b] >> 8) & 255u) * (1.0f / 255.0f)) * cold[7]);
+                            const uint32_t b8 = toU8(((float)((texel[b] >> 16) & 255u) * (1.0f / 255.0f)) * cold[8]);
+                            rgba[hf][b] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
+                        }
+                }
+            }
             if (!(p.debugSkip & 128u)) MRX_STAMP(5);
             if (allDone)
                 break;                                // (the next pass, if any, opens with a barrier)

@@ -468,6 +468,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         }
         if (tm.tex < 0 || (uint32_t)tm.tex >= (uint32_t)texDescs.size())
             tm.tex = -1;
+        if (tm.tex >= 0) {
+            // the texture's descriptor rides along (BVH path: no second load level per pixel)
+            tm.texDesc[0] = (int32_t)texDescs[tm.tex].offset;
+            tm.texDesc[1] = (int32_t)texDescs[tm.tex].width;
+            tm.texDesc[2] = (int32_t)texDescs[tm.tex].height;
+        }
     }
     // S6b: orientation and padded bounding box of every triangle's shell
     for (size_t o = 0; o < r.objFirst.size(); ++o)

@@ -30,7 +30,7 @@ struct alignas(16) TriMat {
     float orient;
     float bbMin[3];
     float bbMax[3];
-    int32_t pad[4];
+    int32_t texDesc[4];   // TexDesc of `tex` (offset, width, height, 0), zero when untextured
 };
 static_assert(sizeof(TriMat) == 64, "TriMat layout");
 

@@ -12,7 +12,7 @@ from madrona_renderer_amd import scenes
 from tests import meshes
 cubes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 worlds = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-desc = meshes.cube_field(worlds, cubes)
+desc = meshes.cube_field(worlds, cubes, textured=os.environ.get('TEXTURED') == '1')
 r = scenes.make_renderer(desc)
 print('%.1f us/step' % (r.time_renders(100) / 100 * 1000))
 for _ in range(5):
