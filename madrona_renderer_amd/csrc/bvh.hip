@@ -56,6 +56,32 @@ __device__ __forceinline__ float rfl(float v)
 }
 __device__ __forceinline__ uint32_t rflu(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Inclusive prefix sum over the 64 lanes in six DPP adds: shifts by 1, 2, 4, 8 within
+// the rows of 16, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2, 3
+// (row_bcast exists on gfx9 / CDNA).  Lanes a step does not reach add the `old` value 0.
+__device__ __forceinline__ int waveInclusiveSum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Camera rotation / position of a view and the light direction in its frame (S2, S4).
+__device__ __forceinline__ void loadViewConst(const RasterParams &p, uint32_t view, ViewConst &vc)
+{
+    const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * view);
+    quatToMat(q.x, q.y, q.z, q.w, vc.Rc);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        vc.c[r] = p.camPos[3 * view + r];
+        vc.lv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r], p.toLight[0], p.toLight[1], p.toLight[2]);
+    }
+}
+
 // One corner of a box under MV / tv: its image position in pixels, and whether it
 // lies safely in front of the eye plane (far enough, relative to the size of
 // the terms it is summed from, for the quotient to be meaningful).
@@ -138,7 +164,6 @@ __device__ __forceinline__ Rect sphereRect(const RasterParams &p, const InstXfor
 // ---------------------------------------------------------------------------
 constexpr int kSlotBits = 10;
 constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
-constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kBigRound = 8;                    // in-wave fallback: large triangles per round
 
 
@@ -160,20 +185,6 @@ static_assert(kBigRound * 64 <= kWave * 8, "fallback records alias the consumed 
 __device__ __forceinline__ unsigned long long packHit(float it, uint32_t low)
 {
     return ((unsigned long long)__float_as_uint(it) << 32) | low;
-}
-
-// One pixel of the lane against one (large) triangle of the round.
-__device__ __forceinline__ void pixelTestKey(const PlanePairs &q, f32x2 r01, f32x2 r2d, float px,
-                                             float invNear, uint32_t lowv, float &best, uint32_t &low)
-{
-    const f32x2 pp = { px, px };
-    const f32x2 e01 = fma2(q.A01, pp, r01);       // e0, e1
-    const f32x2 e2d = fma2(q.A2D, pp, r2d);       // e2, 1/depth
-    const float it = e2d.y;
-    const bool closer = (it > best) | ((it == best) & (lowv > low));
-    const bool in = (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f) & closer & (it <= invNear);
-    best = in ? it : best;
-    low = in ? lowv : low;
 }
 
 // IDS: 0 = no id tensor, 1 = visibility ids (world-local triangle index),
@@ -213,24 +224,20 @@ void bvhTileKernel(const RasterParams p)
     unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [TH][TW]
     float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + TW * TH);                         // [kCap] rgba tex obj k
     float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [8]
-    float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 8);                   // [kBigCap] planes, key, box
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [16]: counters, [8..10] light direction
+    float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 16);                  // [kBigCap] planes, key, box
     float *instRec = reinterpret_cast<float *>(bigList + kBigCap);                      // [passInst][24]
     float4 *instRect = reinterpret_cast<float4 *>(instRec + (size_t)passInst * kInstRecDw);
     WaveScratch *ws = reinterpret_cast<WaveScratch *>(instRect + passInst) + wave;
 
-    // ---- view constants (wave-uniform)
-    ViewConst vc;
-    {
-        const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * view);
-        quatToMat(q.x, q.y, q.z, q.w, vc.Rc);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            vc.c[r] = p.camPos[3 * view + r];
-            vc.lv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r],
-                            p.toLight[0], p.toLight[1], p.toLight[2]);
-        }
-    }
+    // ---- view constants (wave-uniform).  Two placements, picked by what measured faster:
+    //      the untextured instantiations work them out in every wave, here; the textured
+    //      ones (which spill) only in the waves that transform instances, inside the pass
+    //      loop, with the light direction handed to the set-up of all waves through LDS.
+    constexpr bool kLvInLds = TEX;
+    ViewConst vcAll = {};
+    if (!kLvInLds)
+        loadViewConst(p, view, vcAll);
     // (uniform worlds: arithmetic instead of two dependent loads)
     uint32_t i0, i1;
     if (p.bvhUniInst) {
@@ -288,6 +295,17 @@ void bvhTileKernel(const RasterParams p)
         //      64^2 ... 256^2 views, 482 ... 4994 triangles: the sphere wins by 3-5 % everywhere.)
         //      The object's range, root and box were copied per instance at load: no load
         //      depends on another here (an instance whose object id is negative this step is hidden).
+        //      (textured instantiations: only the waves that have instances to transform work
+        //      out the view constants; wave 0 always does, and leaves the light direction in LDS)
+        ViewConst vc = vcAll;
+        if (kLvInLds && (uint32_t)wave * kWave < n) {
+            loadViewConst(p, view, vc);
+            if (threadIdx.x == 0) {
+                ctrl[8] = __float_as_uint(vc.lv[0]);
+                ctrl[9] = __float_as_uint(vc.lv[1]);
+                ctrl[10] = __float_as_uint(vc.lv[2]);
+            }
+        }
         for (uint32_t ch = (uint32_t)wave; ch * kWave < n; ch += kBvhWaves) {
             const uint32_t li = ch * kWave + (uint32_t)lane;
             const bool has = li < n;
@@ -455,7 +473,12 @@ void bvhTileKernel(const RasterParams p)
                     x.sc[0] = a4.x; x.sc[1] = a4.y; x.sc[2] = a4.z;
                     objL = __float_as_int(a4.w);
                     kTri = __float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y));
-                    const bool valid = setupTriangleCore(p, vc.lv, x, e.y, objL, (int32_t)kTri, c, shade, cold);
+                    // (the light direction comes from LDS batch by batch: held in registers it
+                    // costs scalar spills in every loop below)
+                    const float lv[3] = { kLvInLds ? __uint_as_float(ctrl[8]) : vcAll.lv[0],
+                                          kLvInLds ? __uint_as_float(ctrl[9]) : vcAll.lv[1],
+                                          kLvInLds ? __uint_as_float(ctrl[10]) : vcAll.lv[2] };
+                    const bool valid = setupTriangleCore(p, lv, x, e.y, objL, (int32_t)kTri, c, shade, cold);
                     live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
                 }
                 // -- shading records only for triangles that can own a pixel of the tile
@@ -503,12 +526,7 @@ void bvhTileKernel(const RasterParams p)
                     //    four pixels per step -- every lane has a row, however uneven the boxes
                     {
                         const int rowsMine = (small && !(p.debugSkip & 32u)) ? bh : 0;
-                        int incl = rowsMine;
-#pragma unroll
-                        for (int d = 1; d < kWave; d <<= 1) {
-                            const int t = __shfl_up(incl, d);
-                            incl += lane >= d ? t : 0;
-                        }
+                        const int incl = waveInclusiveSum(rowsMine);
                         const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
                         const int packedBox = ix0 | (bw << 16);        // (both < 2^15)
                         for (int item0 = 0; item0 < total; item0 += kWave) {
@@ -607,15 +625,9 @@ void bvhTileKernel(const RasterParams p)
                                                     iy0 <= RY0 + 7 && iy0 + bh > RY0);
                             if (act == 0)
                                 continue;
-                            float best[kRegionBlocks];
-                            uint32_t low[kRegionBlocks];
-#pragma unroll
-                            for (int b = 0; b < kRegionBlocks; ++b) {
-                                best[b] = invFar;
-                                low[b] = kNoHit;             // larger than any key: no tie with "nothing yet"
-                            }
                             const float py = (float)(RY0 + ly);
                             const f32x2 yy = { py, py };
+                            unsigned long long *zrow = zbuf + (8 * strip + ly) * TW + 32 * hf + 4 * lx;
                             for (; act != 0; act &= act - 1) {
                                 const int l = __builtin_ctzll(act);
                                 const int ent = __builtin_popcountll(roundMask & ((1ull << l) - 1ull));
@@ -624,15 +636,15 @@ void bvhTileKernel(const RasterParams p)
                                 const f32x2 r01 = fma2(q.B01, yy, q.C01);
                                 const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
 #pragma unroll
-                                for (int b = 0; b < kRegionBlocks; ++b)
-                                    pixelTestKey(q, r01, r2d, (float)(RX0 + 4 * lx + b), invNear, lowv,
-                                                 best[b], low[b]);
+                                for (int b = 0; b < kRegionBlocks; ++b) {
+                                    const float px = (float)(RX0 + 4 * lx + b);
+                                    const f32x2 pp = { px, px };
+                                    const f32x2 e01 = fma2(q.A01, pp, r01);
+                                    const f32x2 e2d = fma2(q.A2D, pp, r2d);
+                                    if (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f && e2d.y > invFar && e2d.y <= invNear)
+                                        atomicMax(zrow + b, packHit(e2d.y, lowv));
+                                }
                             }
-                            unsigned long long *zrow = zbuf + (8 * strip + ly) * TW + 32 * hf + 4 * lx;
-#pragma unroll
-                            for (int b = 0; b < kRegionBlocks; ++b)
-                                if (low[b] != kNoHit)
-                                    atomicMax(zrow + b, packHit(best[b], low[b]));
                         }
                     }
                     waveLdsSync();
@@ -681,15 +693,13 @@ void bvhTileKernel(const RasterParams p)
                         uint64_t act = __ballot(rows && bx0 <= 32 * hf + 31 && bx1 >= 32 * hf);
                         if (act == 0)
                             continue;
-                        float best[kRegionBlocks];
-                        uint32_t low[kRegionBlocks];
-#pragma unroll
-                        for (int b = 0; b < kRegionBlocks; ++b) {
-                            best[b] = invFar;
-                            low[b] = kNoHit;
-                        }
+                        // every covered pixel goes straight to the depth buffer: the 64-bit
+                        // maximum orders (1/depth, then lower index) by itself, which a
+                        // register copy of the running best would need two more compares
+                        // and two selects per test to imitate
                         const float py = (float)(tileY0 + 8u * wave + ly);
                         const f32x2 yy = { py, py };
+                        unsigned long long *zrow = zbuf + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
                         for (; act != 0; act &= act - 1) {
                             const int l = (int)e0 + __builtin_ctzll(act);
                             const PlanePairs q = loadPlanes(bigList, l);
@@ -697,15 +707,15 @@ void bvhTileKernel(const RasterParams p)
                             const f32x2 r01 = fma2(q.B01, yy, q.C01);
                             const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
 #pragma unroll
-                            for (int b = 0; b < kRegionBlocks; ++b)
-                                pixelTestKey(q, r01, r2d, (float)(tileX0 + 32 * hf + 4 * lx + b), invNear, lowv,
-                                             best[b], low[b]);
+                            for (int b = 0; b < kRegionBlocks; ++b) {
+                                const float px = (float)(tileX0 + 32 * hf + 4 * lx + b);
+                                const f32x2 pp = { px, px };
+                                const f32x2 e01 = fma2(q.A01, pp, r01);       // e0, e1
+                                const f32x2 e2d = fma2(q.A2D, pp, r2d);       // e2, 1/depth
+                                if (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f && e2d.y > invFar && e2d.y <= invNear)
+                                    atomicMax(zrow + b, packHit(e2d.y, lowv));
+                            }
                         }
-                        unsigned long long *zrow = zbuf + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
-#pragma unroll
-                        for (int b = 0; b < kRegionBlocks; ++b)
-                            if (low[b] != kNoHit)
-                                atomicMax(zrow + b, packHit(best[b], low[b]));
                     }
                 }
             }
@@ -832,7 +842,7 @@ namespace {
 size_t ldsFor(uint32_t passInst, bool textured, int tw, int th)
 {
     const size_t cap = (size_t)tabCap(textured, tw, th);
-    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 32 + (size_t)bigCap(tw, th) * 64 +
+    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th) * 64 +
            (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + sizeof(WaveScratch) * (size_t)(th / 8);
 }
 }  // namespace
