@@ -82,12 +82,14 @@ __device__ __forceinline__ void loadViewConst(const RasterParams &p, uint32_t vi
     }
 }
 
-// One corner of a box under MV / tv: its image position in pixels, and whether it
+// One corner of a box under MV / tv: its image position in pixels, whether it
 // lies safely in front of the eye plane (far enough, relative to the size of
-// the terms it is summed from, for the quotient to be meaningful).
+// the terms it is summed from, for the quotient to be meaningful), and whether
+// it lies safely behind it.
 __device__ __forceinline__ void projectCorner(const RasterParams &p, const float (&MV)[3][3],
                                               const float (&tv)[3], float cx, float cy, float cz,
-                                              float isx, float isz, float &fx, float &fz, bool &front)
+                                              float isx, float isz, float &fx, float &fz, bool &front,
+                                              bool &behind)
 {
     float P[3];
 #pragma unroll
@@ -95,6 +97,8 @@ __device__ __forceinline__ void projectCorner(const RasterParams &p, const float
         P[r] = __builtin_fmaf(MV[r][2], cz, __builtin_fmaf(MV[r][1], cy, __builtin_fmaf(MV[r][0], cx, tv[r])));
     const float scale = fabsf(MV[1][0] * cx) + fabsf(MV[1][1] * cy) + fabsf(MV[1][2] * cz) + fabsf(tv[1]);
     front = P[1] > 1e-3f * scale && P[1] > 1e-6f;
+    // safely behind the eye plane: a box whose eight corners all are holds nothing visible
+    behind = P[1] < -1e-3f * scale;
     const float iw = __builtin_amdgcn_rcpf(P[1]);
     fx = (P[0] * iw - p.ox) * isx;
     fz = (P[2] * iw - p.oz) * isz;
@@ -147,7 +151,12 @@ __device__ __forceinline__ Rect sphereRect(const RasterParams &p, const InstXfor
     const float qzl = zl * (zl >= 0.0f ? ifa : in), qzh = zh * (zh >= 0.0f ? in : ifa);
     const float fa = (qxl - p.ox) * isx, fb = (qxh - p.ox) * isx;
     const float ga = (qzl - p.oz) * isz, gb = (qzh - p.oz) * isz;
-    return finishRect(p, fminf(fa, fb), fmaxf(fa, fb), fminf(ga, gb), fmaxf(ga, gb), front);
+    Rect r = finishRect(p, fminf(fa, fb), fmaxf(fa, fb), fminf(ga, gb), fmaxf(ga, gb), front);
+    if (yf < 0.0f) {                                  // the whole sphere behind the eye plane: nothing visible
+        r.x0 = r.y0 = __builtin_inff();
+        r.x1 = r.y1 = -__builtin_inff();
+    }
+    return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -226,9 +235,9 @@ void bvhTileKernel(const RasterParams p)
     float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [16]: counters, [8..10] light direction
     float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 16);                  // [kBigCap] planes, key, box
-    float *instRec = reinterpret_cast<float *>(bigList + kBigCap);                      // [passInst][24]
+    WaveScratch *ws = reinterpret_cast<WaveScratch *>(bigList + kBigCap) + wave;      // (fixed offsets first)
+    float *instRec = reinterpret_cast<float *>(ws - wave + kBvhWaves);                  // [passInst][24]
     float4 *instRect = reinterpret_cast<float4 *>(instRec + (size_t)passInst * kInstRecDw);
-    WaveScratch *ws = reinterpret_cast<WaveScratch *>(instRect + passInst) + wave;
 
     // ---- view constants (wave-uniform).  Two placements, picked by what measured faster:
     //      the untextured instantiations work them out in every wave, here; the textured
@@ -343,7 +352,6 @@ void bvhTileKernel(const RasterParams p)
         uint64_t instMask = 0;
         uint32_t vFirst = 0, vNum = 0;                // of the lane's instance of the current TLAS chunk
         int32_t vRoot = -1;
-        float sMV[3][3] = {}, sTv[3] = {};
         bool done = (p.debugSkip & 4u) != 0;          // timing aid: no traversal at all
         bool reported = false;
         // the record and large-triangle counters alternate between two sets from
@@ -374,10 +382,16 @@ void bvhTileKernel(const RasterParams p)
                             const float cy = (corner & 2) ? nd->bmax[c][1] : nd->bmin[c][1];
                             const float cz = (corner & 4) ? nd->bmax[c][2] : nd->bmin[c][2];
                             float fx, fz;
-                            bool f;
-                            projectCorner(p, sMV, sTv, cx, cy, cz, isx, isz, fx, fz, f);
+                            bool f, bh;
+                            // (the instance's transform comes from its TLAS record per visit: kept in
+                            // scalar registers across the loops it cost twelve of them, spilled)
+                            const float4 *irec = reinterpret_cast<const float4 *>(instRec + (size_t)curInst * kInstRecDw);
+                            const float4 a0 = irec[0], a1 = irec[1], a2 = irec[2];
+                            const float nMV[3][3] = { { a0.x, a0.y, a0.z }, { a0.w, a1.x, a1.y }, { a1.z, a1.w, a2.x } };
+                            const float nTv[3] = { a2.y, a2.z, a2.w };
+                            projectCorner(p, nMV, nTv, cx, cy, cz, isx, isz, fx, fz, f, bh);
                             float x0 = fx, x1 = fx, z0 = fz, z1 = fz;
-                            int fr = f ? 1 : 0;
+                            int fr = (f ? 1 : 0) | (bh ? 2 : 0);
 #pragma unroll
                             for (int m = 1; m < 8; m <<= 1) {
                                 x0 = fminf(x0, __shfl_xor(x0, m));
@@ -386,10 +400,12 @@ void bvhTileKernel(const RasterParams p)
                                 z1 = fmaxf(z1, __shfl_xor(z1, m));
                                 fr &= __shfl_xor(fr, m);
                             }
-                            const Rect r = finishRect(p, x0, x1, z0, z1, fr != 0);
+                            const Rect r = finishRect(p, x0, x1, z0, z1, (fr & 1) != 0);
                             // the root's children are dealt one per wave
+                            // (a child entirely behind the eye plane is dropped -- otherwise its
+                            // unbounded rectangle would send all its triangles to the leaf test)
                             const bool hit = cref != kBvhEmpty && corner == 0 && (!isRoot || (c & (kBvhWaves - 1)) == wave) &&
-                                             overlaps(r, TX0, TX1, TY0, TY1);
+                                             !(fr & 2) && overlaps(r, TX0, TX1, TY0, TY1);
                             uint64_t hm = __ballot(hit);
                             while (hm) {
                                 const int l = __builtin_ctzll(hm);
@@ -413,14 +429,6 @@ void bvhTileKernel(const RasterParams p)
                                 ws->queue[qCount + lane] = make_uint2(curInst, first + lane);
                             qCount += num;
                         } else {
-                            const float *rec = instRec + (size_t)curInst * kInstRecDw;
-#pragma unroll
-                            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                                for (int cc = 0; cc < 3; ++cc)
-                                    sMV[r][cc] = rfl(rec[3 * r + cc]);
-                                sTv[r] = rfl(rec[9 + r]);
-                            }
                             ws->stack[sp++] = (uint32_t)root | kRootFlag;
                             waveLdsSync();
                         }
@@ -480,6 +488,18 @@ void bvhTileKernel(const RasterParams p)
                                           kLvInLds ? __uint_as_float(ctrl[10]) : vcAll.lv[2] };
                     const bool valid = setupTriangleCore(p, lv, x, e.y, objL, (int32_t)kTri, c, shade, cold);
                     live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
+                    // The planes at the tile's corners: fl(A x + fl(B y + C)) is monotone in x and in
+                    // y, so its extreme over the tile's pixels is taken at a corner pixel, and a
+                    // triangle with an edge plane negative, or 1/depth outside (1/zfar, 1/znear], at
+                    // the most favourable corner owns no pixel of the tile -- exactly, not
+                    // approximately.  This is what drops triangles behind the eye (their box is
+                    // unbounded: they would all count as large) and boxes that only graze the tile.
+                    const float eMax0 = __builtin_fmaf(c.A0, c.A0 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B0, c.B0 >= 0.0f ? TY1 : TY0, c.C0));
+                    const float eMax1 = __builtin_fmaf(c.A1, c.A1 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B1, c.B1 >= 0.0f ? TY1 : TY0, c.C1));
+                    const float eMax2 = __builtin_fmaf(c.A2, c.A2 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B2, c.B2 >= 0.0f ? TY1 : TY0, c.C2));
+                    const float itMax = __builtin_fmaf(c.Dx, c.Dx >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.Dy, c.Dy >= 0.0f ? TY1 : TY0, c.Dc));
+                    const float itMin = __builtin_fmaf(c.Dx, c.Dx >= 0.0f ? TX0 : TX1, __builtin_fmaf(c.Dy, c.Dy >= 0.0f ? TY0 : TY1, c.Dc));
+                    live = live && fminf(fminf(eMax0, eMax1), eMax2) >= 0.0f && itMax > invFar && itMin <= invNear;
                 }
                 // -- shading records only for triangles that can own a pixel of the tile
                 //    (about half the candidates are back faces): slots by rank among them

@@ -16,6 +16,7 @@ if len(sys.argv) > 2:
     os.environ["MRX_BVH_SMALL_AREA"] = sys.argv[2]
 desc = {"cubes40": lambda: meshes.cube_field(1024, 40),
         "cubes100": lambda: meshes.cube_field(1024, 100),
+        "meshes": lambda: meshes.mesh_worlds(256),
         "hl": lambda: scenes.synthetic_scene(4096)}[which]()
 for skip, name in ((0, "full"), (1, "no stores"), (32, "no small-triangle walk"), (64, "no large-triangle pass"),
                    (2, "no pixel tests"), (2 | 8, "no setup, no pixel tests"),
@@ -25,7 +26,8 @@ for skip, name in ((0, "full"), (1, "no stores"), (32, "no small-triangle walk")
     r = scenes.make_renderer(desc)
     t0 = time.time()
     while time.time() - t0 < 0.2:
-        r.time_renders(20)
-    us = min(r.time_renders(100) for _ in range(3)) * 10.0
+        r.time_renders(5)
+    n = 10 if which == "meshes" else 100
+    us = min(r.time_renders(n) for _ in range(3)) * 1000.0 / n
     print("%-46s %8.1f us" % (name, us), flush=True)
     del r

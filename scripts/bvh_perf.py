@@ -42,6 +42,8 @@ def main():
         cases = cases[:4] + [("1024 x 64^2, 40 textured cubes", meshes.cube_field(1024, 40, textured=True), 200),
                              ("64 x 256^2 RT, 416 cubes", meshes.cube_field(64, 416, width=256, height=256, mode="Raytracer"), 50),
                              ("256 x 128^2, 40 cubes", meshes.cube_field(256, 40, width=128, height=128), 100),
+                             ("256 x 64^2, meshes (14152 tris, BLAS)", meshes.mesh_worlds(256), 50),
+                             ("64 x 256^2 RT, meshes (BLAS)", meshes.mesh_worlds(64, 256, 256, "Raytracer"), 30),
                              # close-ups: every triangle is large
                              ("1024 x 64^2, cube+plane (14 tris)", scenes.synthetic_scene(1024), 200),
                              ("1024 x 128^2, cube+plane+wall", scenes.synthetic_scene(1024, width=128, height=128, with_wall=True), 50)]

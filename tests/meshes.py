@@ -111,3 +111,30 @@ def cube_field(num_worlds, cubes, width=64, height=64, mode="Rasterizer", textur
         asset_paths=[(CUBE, 0), (PLANE, 1)], materials=mats,
         texture_paths=[os.path.join(scenes.DATA_DIR, "cube.png")],
         instances=inst, cameras=cams, worlds=worlds)
+
+
+def mesh_worlds(num_worlds, width=64, height=64, mode="Rasterizer", seed=3):
+    """Worlds of large meshes (terrain 9800 + torus 2304 + two spheres of 1024 triangles = 14,152 per
+    world, three-level BLASes), one camera per world on a ring: the shape of world the BLAS
+    traversal exists for (perf scripts; tests/test_bvh_gpu.py has the parity scene)."""
+    sph, tor, ter = sphere(32, 16), torus(48, 24), terrain(70)
+    geo = pack_meshes([(sph[0], sph[1], sph[2], 0), (tor[0], tor[1], tor[2], 1), (ter[0], ter[1], ter[2], 2)])
+    inst, cams, worlds = [], [], []
+    for w in range(num_worlds):
+        rng = np.random.default_rng(seed * 7919 + w)
+        i0 = len(inst)
+        inst.append(((0.0, 0.0, -1.0), IDENT, (1.0, 1.0, 1.0), 2))
+        inst.append(((0.0, 0.0, 2.5), random_quat(rng), (1.5, 1.0, 0.7), 1))
+        for _ in range(2):
+            p = rng.uniform(-6, 6, 2)
+            inst.append(((float(np.float32(p[0])), float(np.float32(p[1])), 2.0), random_quat(rng), (1.2, 1.2, 1.2), 0))
+        az = float(rng.uniform(0, 2 * math.pi))
+        r, h = float(rng.uniform(9, 20)), float(rng.uniform(3, 12))
+        eye = tuple(float(np.float32(x)) for x in (r * math.cos(az), r * math.sin(az), h))
+        cams.append((eye, scenes.look_at(eye, (0.0, 0.0, 1.0))))
+        worlds.append((4, i0, 1, len(cams) - 1))
+    return scenes.SceneDesc(
+        num_worlds=num_worlds, render_mode=mode, width=width, height=height, asset_paths=[],
+        materials=[((0.9, 0.8, 0.7, 1.0), -1, 0.5, 0.5), ((0.3, 0.5, 0.9, 1.0), -1, 0.5, 0.5),
+                   ((0.4, 0.7, 0.3, 1.0), -1, 0.5, 0.5)],
+        instances=inst, cameras=cams, worlds=worlds, **geo)
