@@ -534,7 +534,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // ahead, 482 triangles 2x -- profiles/r02_bvh_crossover.txt); it serves both
     // render modes.  MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3
     // force the BVH / the raster kernels.
-    uint32_t bvhMinTris = 192;
+    uint32_t bvhMinTris = 160;
     if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
         bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);
