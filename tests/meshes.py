@@ -138,3 +138,39 @@ def mesh_worlds(num_worlds, width=64, height=64, mode="Rasterizer", seed=3):
         materials=[((0.9, 0.8, 0.7, 1.0), -1, 0.5, 0.5), ((0.3, 0.5, 0.9, 1.0), -1, 0.5, 0.5),
                    ((0.4, 0.7, 0.3, 1.0), -1, 0.5, 0.5)],
         instances=inst, cameras=cams, worlds=worlds, **geo)
+
+
+def mesh_scene_random_cameras(seed, width, height, mode):
+    """Two worlds of terrain / torus / spheres (three-level BLASes) seen by eight random cameras: on the
+    terrain, inside or next to an object's box, on a ring, anywhere looking anywhere -- the cases the BVH
+    path's behind-the-eye culling and tile-corner classification decide."""
+    rng = np.random.default_rng(seed)
+    sph, tor, ter = sphere(24, 12), torus(32, 16), terrain(40)
+    geo = pack_meshes([(sph[0], sph[1], sph[2], 0), (tor[0], tor[1], tor[2], 1), (ter[0], ter[1], ter[2], 2)])
+    inst = [((0.0, 0.0, -1.0), IDENT, (1.0, 1.0, 1.0), 2),
+            ((0.0, 0.0, 2.5), random_quat(rng), (1.5, 1.0, 0.7), 1),
+            ((4.0, -3.0, 2.0), random_quat(rng), (1.2, -1.2, 1.2), 0),
+            ((-5.0, 2.0, 1.5), random_quat(rng), tuple(float(x) for x in rng.uniform(0.3, 2.0, 3)), 0)]
+    cams = []
+    for _ in range(8):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:       # on / just above the terrain, looking along it
+            eye = (float(rng.uniform(-12, 12)), float(rng.uniform(-12, 12)), float(rng.uniform(-0.8, 1.5)))
+            tgt = (float(rng.uniform(-12, 12)), float(rng.uniform(-12, 12)), float(rng.uniform(-1, 3)))
+            cams.append((eye, scenes.look_at(eye, tgt)))
+        elif kind == 1:     # inside / next to an object's box
+            c = inst[int(rng.integers(1, 4))][0]
+            eye = tuple(float(np.float32(c[i] + rng.normal() * 0.8)) for i in range(3))
+            cams.append((eye, random_quat(rng)))
+        elif kind == 2:     # ring, looking at the centre
+            az, r, h = rng.uniform(0, 6.28), rng.uniform(3, 25), rng.uniform(0.5, 14)
+            eye = (float(r * math.cos(az)), float(r * math.sin(az)), float(h))
+            cams.append((eye, scenes.look_at(eye, (0.0, 0.0, 1.0))))
+        else:               # anywhere, any direction
+            eye = tuple(float(np.float32(x)) for x in rng.normal(size=3) * 8.0)
+            cams.append((eye, random_quat(rng)))
+    return scenes.SceneDesc(
+        num_worlds=2, render_mode=mode, width=width, height=height, asset_paths=[],
+        materials=[((0.9, 0.8, 0.7, 1.0), -1, 0.5, 0.5), ((0.3, 0.5, 0.9, 1.0), -1, 0.5, 0.5),
+                   ((0.4, 0.7, 0.3, 1.0), -1, 0.5, 0.5)],
+        instances=inst, cameras=cams, worlds=[(4, 0, 5, 0), (3, 0, 3, 5)], **geo)

@@ -134,3 +134,20 @@ def test_random_raw_geometry_scenes_through_the_bvh_path(native, monkeypatch, se
     ref = render_oracle(d)
     assert_parity(got, ref)
     assert (ref["tri_id"] >= 0).mean() > 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,size,mode,tile", [(300, (64, 64), "Rasterizer", 0), (303, (128, 128), "Raytracer", 0),
+                                                 (306, (96, 128), "Rasterizer", 1), (309, (64, 64), "Raytracer", 2),
+                                                 (312, (33, 64), "Rasterizer", 0)])
+def test_mesh_worlds_seen_by_random_cameras(native, monkeypatch, seed, size, mode, tile):
+    # cameras on the terrain, inside object boxes, looking away: triangles behind and across the eye
+    # plane, unbounded boxes (scripts/soak_bvh.py runs 150 such scenes)
+    from tests import meshes
+    monkeypatch.setenv("MRX_BVH_TILE", str(tile))
+    d = meshes.mesh_scene_random_cameras(seed, size[0], size[1], mode)
+    r = make_product(d, visibility=True)
+    assert r.render_path() == "bvh"
+    ref = render_oracle(d)
+    assert_parity(fetch(r), ref)
+    assert (ref["tri_id"] >= 0).mean() > 0.2
