@@ -173,23 +173,19 @@ __device__ __forceinline__ Rect sphereRect(const RasterParams &p, const InstXfor
 // ---------------------------------------------------------------------------
 constexpr int kSlotBits = 10;
 constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
-constexpr int kBigRound = 8;                    // in-wave fallback: large triangles per round
 
 
 // Tile shapes (the LDS tile-size sweep of BASELINE configs[2]): TW x TH pixels per workgroup, one wave per
 // TW x 8 strip, so TH / 8 waves; the depth buffer takes TW * TH * 8 bytes of LDS.
 constexpr int tabCap(bool tex, int tw, int th) { return tex ? 256 : (tw * th >= 4096 ? 1024 : 512); }
-constexpr int bigCap(int tw, int th) { return tw * th >= 4096 ? 96 : 48; }
+constexpr int bigCap(int tw, int th) { return tw * th >= 4096 ? 96 : 64; }   // (>= 64: one batch always fits an empty list)
 
 struct WaveScratch {
-    // (instance of the pass, object triangle).  Once a batch is set up, the
-    // first 64 entries double as eight plane records for the in-wave fallback
-    // of the large-triangle pass.
+    // (instance of the pass, object triangle)
     uint2 queue[kQueueCap];
     uint32_t stack[kBvhStackCap];
 };
 static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch alignment");
-static_assert(kBigRound * 64 <= kWave * 8, "fallback records alias the consumed part of the queue");
 
 __device__ __forceinline__ unsigned long long packHit(float it, uint32_t low)
 {
@@ -538,6 +534,7 @@ void bvhTileKernel(const RasterParams p)
                 const int area = bw * bh;
                 const bool small = live && area <= smallArea;
                 const bool big = live && !small;
+                bool listFull = false;
                 if (!(p.debugSkip & 2u)) {
                     // -- small triangles, by (triangle, row of its box): the rows of all the
                     //    batch's small triangles are numbered through (prefix sum over the
@@ -597,7 +594,7 @@ void bvhTileKernel(const RasterParams p)
                     if (p.debugSkip & 128u) MRX_STAMP(4);
                     // -- large triangles go on the tile's shared list: after the barrier all
                     //    eight waves rasterise them, each its own strip
-                    uint64_t bigMask = __ballot(big && !(p.debugSkip & 64u));
+                    const uint64_t bigMask = __ballot(big && !(p.debugSkip & 64u));
                     const int numBig = __builtin_popcountll(bigMask);
                     const int rank = __builtin_popcountll(bigMask & ((1ull << lane) - 1ull));
                     const uint32_t boxXY = (uint32_t)(ix0 - (int)tileX0) | ((uint32_t)(bw - 1) << 8) |
@@ -615,59 +612,25 @@ void bvhTileKernel(const RasterParams p)
                                 dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
                                 dst[3] = make_float4(__uint_as_float(lowKey), __uint_as_float(boxXY), 0.f, 0.f);
                             }
-                            bigMask = 0;
-                        } else if (bigBase < (uint32_t)kBigCap && (uint32_t)lane < (uint32_t)kBigCap - bigBase) {
-                            // the reservation ran over the end of the list: blank what
-                            // it covers (the pass reads every entry below the count)
-                            reinterpret_cast<float4 *>(bigList[bigBase + lane])[3] =
-                                make_float4(0.f, __uint_as_float(0x00FF0000u), 0.f, 0.f);
-                        }
-                    }
-                    // -- the list is full (a close-up: most triangles are large): this wave
-                    //    rasterises its own, eight at a time, over the whole tile
-                    float (*ownPlanes)[16] = reinterpret_cast<float (*)[16]>(ws->queue);
-                    for (int round = 0; bigMask != 0 && round * kBigRound < numBig; ++round) {
-                        const bool mine = ((bigMask >> lane) & 1ull) && rank / kBigRound == round;
-                        waveLdsSync();
-                        if (mine) {
-                            float4 *dst = reinterpret_cast<float4 *>(ownPlanes[rank % kBigRound]);
-                            dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
-                            dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
-                            dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
-                            dst[3] = make_float4(__uint_as_float(lowKey), 0.f, 0.f, 0.f);
-                        }
-                        waveLdsSync();
-                        const uint64_t roundMask = __ballot(mine);
-                        for (int region = 0; region < kBvhWaves * kHalves; ++region) {
-                            const int strip = region / kHalves, hf = region % kHalves;
-                            const int RX0 = (int)tileX0 + 32 * hf, RY0 = (int)tileY0 + 8 * strip;
-                            uint64_t act = __ballot(mine && ix0 <= RX0 + 31 && ix0 + bw > RX0 &&
-                                                    iy0 <= RY0 + 7 && iy0 + bh > RY0);
-                            if (act == 0)
-                                continue;
-                            const float py = (float)(RY0 + ly);
-                            const f32x2 yy = { py, py };
-                            unsigned long long *zrow = zbuf + (8 * strip + ly) * TW + 32 * hf + 4 * lx;
-                            for (; act != 0; act &= act - 1) {
-                                const int l = __builtin_ctzll(act);
-                                const int ent = __builtin_popcountll(roundMask & ((1ull << l) - 1ull));
-                                const PlanePairs q = loadPlanes(ownPlanes, ent);
-                                const uint32_t lowv = rflu(__float_as_uint(ownPlanes[ent][12]));
-                                const f32x2 r01 = fma2(q.B01, yy, q.C01);
-                                const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
-#pragma unroll
-                                for (int b = 0; b < kRegionBlocks; ++b) {
-                                    const float px = (float)(RX0 + 4 * lx + b);
-                                    const f32x2 pp = { px, px };
-                                    const f32x2 e01 = fma2(q.A01, pp, r01);
-                                    const f32x2 e2d = fma2(q.A2D, pp, r2d);
-                                    if (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f && e2d.y > invFar && e2d.y <= invNear)
-                                        atomicMax(zrow + b, packHit(e2d.y, lowv));
-                                }
-                            }
+                        } else {
+                            // The list is full (a close-up: most triangles are large).  The round ends
+                            // here for this wave and the batch is taken again in the next one, with an
+                            // empty list: everything done for it so far is idempotent (the depth buffer
+                            // takes maxima, records are a function of the triangle), and whoever
+                            // reserves first in a round always fits, so every round makes progress.
+                            // The part of the reservation inside the list is blanked -- the pass reads
+                            // every entry below the count.
+                            if (bigBase < (uint32_t)kBigCap && (uint32_t)lane < (uint32_t)kBigCap - bigBase)
+                                reinterpret_cast<float4 *>(bigList[bigBase + lane])[3] =
+                                    make_float4(0.f, __uint_as_float(0x00FF0000u), 0.f, 0.f);
+                            listFull = true;
                         }
                     }
                     waveLdsSync();
+                }
+                if (listFull) {
+                    tableFull = true;
+                    break;
                 }
                 // -- what did not fit the batch moves to the front of the queue
                 if (qCount > (uint32_t)kWave) {
