@@ -194,7 +194,8 @@ __device__ __forceinline__ unsigned long long packHit(float it, uint32_t low)
 
 // IDS: 0 = no id tensor, 1 = visibility ids (world-local triangle index),
 // 2 = segmask (objectID of the winner's instance)
-template <int IDS, bool TEX, int TW, int TH>
+// CLS: exact per-strip classification of the listed large triangles (64x64 tiles only)
+template <int IDS, bool TEX, int TW, int TH, bool CLS = false>
 __global__ __launch_bounds__(kWave *(TH / 8), 4)
 void bvhTileKernel(const RasterParams p)
 {
@@ -671,9 +672,42 @@ void bvhTileKernel(const RasterParams p)
                     const int bx0 = (int)(box & 255u), bx1 = bx0 + (int)((box >> 8) & 255u);
                     const int by0 = (int)((box >> 16) & 255u), by1 = by0 + (int)(box >> 24);
                     const bool rows = ent < listed && by0 <= 8 * wave + 7 && by1 >= 8 * wave;
+                    // Can the lane's entry touch this wave's strip at all?  Its planes at the most
+                    // favourable corner pixel of each 32x8 half (exact, by monotonicity -- as for the
+                    // whole tile at the leaf test): a triangle that crosses the eye plane has an
+                    // unbounded box but touches few regions, and the two halves of a ground quad
+                    // split the tile between them.
+                    // CLS is a kernel-level switch like TEX: the untextured kernel has no register
+                    // to spare (cube fields lose 2-3 % with the test compiled in, mesh worlds gain
+                    // 27 %), so the host picks the instantiation by whether the scene has meshes
+                    // large enough for a BLAS.
+                    bool reg[kHalves];
+#pragma unroll
+                    for (int hf = 0; hf < kHalves; ++hf)
+                        reg[hf] = true;
+                    if (CLS) {
+                        const float4 *src = reinterpret_cast<const float4 *>(bigList[ent < listed ? ent : 0u]);
+                        const float4 pa = src[0], pb = src[1], pc = src[2];
+                        const float y0 = TY0 + (float)(8 * wave), y1 = y0 + 7.0f;
+                        const float r0 = __builtin_fmaf(pb.x, pb.x >= 0.0f ? y1 : y0, pc.x);
+                        const float r1 = __builtin_fmaf(pb.y, pb.y >= 0.0f ? y1 : y0, pc.y);
+                        const float r2 = __builtin_fmaf(pb.z, pb.z >= 0.0f ? y1 : y0, pc.z);
+                        const float dMax = __builtin_fmaf(pb.w, pb.w >= 0.0f ? y1 : y0, pc.w);
+                        const float dMin = __builtin_fmaf(pb.w, pb.w >= 0.0f ? y0 : y1, pc.w);
+#pragma unroll
+                        for (int hf = 0; hf < kHalves; ++hf) {
+                            const float x0 = TX0 + (float)(32 * hf), x1 = x0 + 31.0f;
+                            const float e0 = __builtin_fmaf(pa.x, pa.x >= 0.0f ? x1 : x0, r0);
+                            const float e1 = __builtin_fmaf(pa.y, pa.y >= 0.0f ? x1 : x0, r1);
+                            const float e2 = __builtin_fmaf(pa.z, pa.z >= 0.0f ? x1 : x0, r2);
+                            const float iMax = __builtin_fmaf(pa.w, pa.w >= 0.0f ? x1 : x0, dMax);
+                            const float iMin = __builtin_fmaf(pa.w, pa.w >= 0.0f ? x0 : x1, dMin);
+                            reg[hf] = fminf(fminf(e0, e1), e2) >= 0.0f && iMax > invFar && iMin <= invNear;
+                        }
+                    }
 #pragma unroll
                     for (int hf = 0; hf < kHalves; ++hf) {
-                        uint64_t act = __ballot(rows && bx0 <= 32 * hf + 31 && bx1 >= 32 * hf);
+                        uint64_t act = __ballot(rows && reg[hf] && bx0 <= 32 * hf + 31 && bx1 >= 32 * hf);
                         if (act == 0)
                             continue;
                         // every covered pixel goes straight to the depth buffer: the 64-bit
@@ -843,23 +877,24 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     const uint32_t items = p.numViews * ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
     const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th);
     const dim3 grid(items), block(kWave * (th / 8));
-#define MRX_BVH(I, T, W, H)                                                                    \
+#define MRX_BVH(I, T, W, H, C)                                                                 \
     do {                                                                                       \
         static size_t allowed = 0;                                                             \
         if (lds > allowed) {                                                                   \
-            const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H>,  \
+            const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H, C>, \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess)                                                               \
                 return e;                                                                      \
             allowed = lds;                                                                     \
         }                                                                                      \
-        bvhTileKernel<I, T, W, H><<<grid, block, lds, stream>>>(p);                            \
+        bvhTileKernel<I, T, W, H, C><<<grid, block, lds, stream>>>(p);                         \
     } while (0)
 #define MRX_BVH_SHAPE(I, T)                                                                    \
     do {                                                                                       \
-        if (p.bvhTile == 0) MRX_BVH(I, T, 64, 64);                                             \
-        else if (p.bvhTile == 1) MRX_BVH(I, T, 64, 32);                                        \
-        else MRX_BVH(I, T, 32, 32);                                                            \
+        if (p.bvhTile == 0 && p.bvhClassify) MRX_BVH(I, T, 64, 64, true);                      \
+        else if (p.bvhTile == 0) MRX_BVH(I, T, 64, 64, false);                                 \
+        else if (p.bvhTile == 1) MRX_BVH(I, T, 64, 32, false);                                 \
+        else MRX_BVH(I, T, 32, 32, false);                                                     \
     } while (0)
     if (ids == 2) {
         if (tex) MRX_BVH_SHAPE(2, true); else MRX_BVH_SHAPE(2, false);

@@ -758,6 +758,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.bvhTile = 0;
     if (const char *dbg = std::getenv("MRX_BVH_TILE"))
         p.bvhTile = std::max(0, std::min(2, std::atoi(dbg)));
+    // scenes with meshes large enough for a BLAS get the instantiation that classifies the
+    // listed large triangles per strip (bvh.hip, CLS): close-ups of such meshes are where
+    // long lists of large triangles come from
+    p.bvhClassify = blas.nodes.empty() ? 0 : 1;
+    if (const char *dbg = std::getenv("MRX_BVH_CLASSIFY"))
+        p.bvhClassify = std::atoi(dbg) != 0;
     p.bvhSmallArea = 32;
     if (const char *dbg = std::getenv("MRX_BVH_SMALL_AREA"))
         p.bvhSmallArea = std::max(0, std::min(4096, std::atoi(dbg)));

@@ -137,6 +137,7 @@ struct RasterParams {
     uint32_t bvhPassInst;            // instances whose TLAS records fit LDS at once (multiple of 64)
     int32_t bvhTile;                 // tile of a workgroup: 0 = 64x64, 1 = 64 wide x 32, 2 = 32x32 (MRX_BVH_TILE)
     int32_t bvhSmallArea;            // boxes of up to this many pixels are walked by their triangle's lane
+    int32_t bvhClassify;             // 64x64 tiles: the instantiation that classifies listed triangles per strip
 };
 
 // Kernel variants (mrx_config.kernel_variant).

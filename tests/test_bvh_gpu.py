@@ -290,3 +290,29 @@ def test_tile_shapes_of_the_lds_depth_buffer_give_the_same_bytes(native, monkeyp
     else:
         d = scenes.synthetic_scene(12, width=128, height=128, with_wall=True)
     _parity(d, variant=BVH)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classify", [0, 1])
+@pytest.mark.parametrize("case", ["cubes", "meshes", "close-up"])
+def test_strip_classification_of_large_triangles_is_exact(native, monkeypatch, case, classify):
+    # the CLS instantiation (chosen by the host for scenes with BLAS meshes) and the plain
+    # one give the oracle's bytes on scenes of either kind, and on a close-up where every
+    # triangle is large and the list overflows (the round ends, the batch is taken again)
+    monkeypatch.setenv("MRX_BVH_CLASSIFY", str(classify))
+    if case == "cubes":
+        d = meshes.cube_field(24, 40)
+    elif case == "meshes":
+        d = meshes.mesh_scene_random_cameras(321, 64, 64, "Rasterizer")
+    else:
+        # a camera inside a cube field scaled up: hundreds of large triangles per tile
+        base = meshes.cube_field(6, 60, spread=3.0)
+        d = scenes.SceneDesc(
+            num_worlds=base.num_worlds, render_mode="Raytracer", width=64, height=64, asset_paths=base.asset_paths,
+            materials=base.materials, texture_paths=base.texture_paths,
+            instances=[(p_, q_, (s_[0] * 3.0, s_[1] * 3.0, s_[2] * 3.0), o_) for p_, q_, s_, o_ in base.instances],
+            cameras=[((c[0][0] * 0.2, c[0][1] * 0.2, 1.0), c[1]) for c in base.cameras], worlds=base.worlds)
+    r = make_product(d, visibility=True, variant=2)
+    ref = render_oracle(d)
+    assert_parity(fetch(r), ref)
+    assert (ref["tri_id"] >= 0).mean() > 0.3
