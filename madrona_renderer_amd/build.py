@@ -78,6 +78,9 @@ def build_hip(force=False, verbose=False, extra_flags=()):
                "-fno-slp-vectorize",
                "-Wall", "-Wno-unused-function"]
         cmd += list(extra_flags)
+        # e.g. MRX_EXTRA_HIPCC_FLAGS=-DMRX_BVH_DIAG=1 python -m madrona_renderer_amd.build --force
+        # (the BVH kernel's in-kernel stamps and phase switches: scripts/bvh_stamps.py, bvh_ablate.py)
+        cmd += os.environ.get("MRX_EXTRA_HIPCC_FLAGS", "").split()
         cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
         cmd += ["-lz", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
         _run(cmd, verbose)

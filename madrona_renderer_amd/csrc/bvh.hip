@@ -171,6 +171,9 @@ __device__ __forceinline__ Rect sphereRect(const RasterParams &p, const InstXfor
 // in-order scan with a strict '>' induces, so the result does not depend on
 // the order the hierarchy is walked in.  A low word of 0 means "no hit".
 // ---------------------------------------------------------------------------
+#ifndef MRX_BVH_DIAG
+#define MRX_BVH_DIAG 0
+#endif
 constexpr int kSlotBits = 10;
 constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
 
@@ -213,14 +216,17 @@ void bvhTileKernel(const RasterParams p)
     const uint32_t tile = blockIdx.x - view * tilesPerView;
     const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
     const uint32_t passInst = p.bvhPassInst;
-    if (p.debugSkip & 16u)
+    const uint32_t dskip = MRX_BVH_DIAG ? p.debugSkip : 0u;
+    if (dskip & 16u)
         return;                                       // timing aid: bare launch
-    // diagnostic (MRX_DEBUG_STAMPS=1): waves 0-3 record 100 MHz stamps of their phases
-    unsigned long long *stamps = (p.debugStamps && wave < 4)
+    // Diagnostics (in-kernel stamps, MRX_DEBUG_STAMPS=1; phases switched off, MRX_DEBUG_SKIP)
+    // exist only in a build with -DMRX_BVH_DIAG=1 (scripts/ab_build.sh diag -DMRX_BVH_DIAG=1):
+    // the flags and the stamp pointer cost scalar registers in loops that have none to spare.
+    unsigned long long *stamps = (MRX_BVH_DIAG && p.debugStamps && wave < 4)
         ? p.debugStamps + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
 #define MRX_STAMP(i)                                                           \
     do {                                                                       \
-        if (stamps && lane == 0)                                               \
+        if (MRX_BVH_DIAG && stamps && lane == 0)                               \
             stamps[i] = __builtin_amdgcn_s_memrealtime();                      \
     } while (0)
     MRX_STAMP(0);
@@ -349,7 +355,7 @@ void bvhTileKernel(const RasterParams p)
         uint64_t instMask = 0;
         uint32_t vFirst = 0, vNum = 0;                // of the lane's instance of the current TLAS chunk
         int32_t vRoot = -1;
-        bool done = (p.debugSkip & 4u) != 0;          // timing aid: no traversal at all
+        bool done = (dskip & 4u) != 0;          // timing aid: no traversal at all
         bool reported = false;
         // the record and large-triangle counters alternate between two sets from
         // round to round, so the idle set can be cleared while the other is read
@@ -454,7 +460,7 @@ void bvhTileKernel(const RasterParams p)
                 // -- a batch of up to 64 candidates.  Leaf test setup, lane = triangle:
                 //    S3-S7 with the instance's transform from the TLAS record.
                 const uint32_t nb = qCount < (uint32_t)kWave ? qCount : (uint32_t)kWave;
-                if (p.debugSkip & 128u) MRX_STAMP(2);
+                if (dskip & 128u) MRX_STAMP(2);
                 bool live = false;
                 TriPlanes c;
                 c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
@@ -464,7 +470,7 @@ void bvhTileKernel(const RasterParams p)
                 int32_t objL = -1;
                 float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
                 float4 texDesc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((uint32_t)lane < nb && !(p.debugSkip & 8u)) {
+                if ((uint32_t)lane < nb && !(dskip & 8u)) {
                     const uint2 e = ws->queue[lane];
                     if (TEX)                          // the texture descriptor stored with the triangle's material
                         texDesc = reinterpret_cast<const float4 *>(p.triMats + e.y)[3];
@@ -523,7 +529,7 @@ void bvhTileKernel(const RasterParams p)
                         coldTab[slot][11] = texDesc.z;
                     }
                 }
-                if (p.debugSkip & 128u) MRX_STAMP(3);
+                if (dskip & 128u) MRX_STAMP(3);
                 // pixel range of the triangle inside the tile: the conservative box
                 // of setup, less all but 1/32 of its one-pixel margin
                 const float kTrim = 0.96875f;
@@ -536,14 +542,14 @@ void bvhTileKernel(const RasterParams p)
                 const bool small = live && area <= smallArea;
                 const bool big = live && !small;
                 bool listFull = false;
-                if (!(p.debugSkip & 2u)) {
+                if (!(dskip & 2u)) {
                     // -- small triangles, by (triangle, row of its box): the rows of all the
                     //    batch's small triangles are numbered through (prefix sum over the
                     //    lanes) and dealt 64 at a time, a lane fetches the planes of its row's
                     //    triangle from the lane that set it up (ds_bpermute) and walks the row
                     //    four pixels per step -- every lane has a row, however uneven the boxes
                     {
-                        const int rowsMine = (small && !(p.debugSkip & 32u)) ? bh : 0;
+                        const int rowsMine = (small && !(dskip & 32u)) ? bh : 0;
                         const int incl = waveInclusiveSum(rowsMine);
                         const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
                         const int packedBox = ix0 | (bw << 16);        // (both < 2^15)
@@ -592,10 +598,10 @@ void bvhTileKernel(const RasterParams p)
                             }
                         }
                     }
-                    if (p.debugSkip & 128u) MRX_STAMP(4);
+                    if (dskip & 128u) MRX_STAMP(4);
                     // -- large triangles go on the tile's shared list: after the barrier all
                     //    eight waves rasterise them, each its own strip
-                    const uint64_t bigMask = __ballot(big && !(p.debugSkip & 64u));
+                    const uint64_t bigMask = __ballot(big && !(dskip & 64u));
                     const int numBig = __builtin_popcountll(bigMask);
                     const int rank = __builtin_popcountll(bigMask & ((1ull << lane) - 1ull));
                     const uint32_t boxXY = (uint32_t)(ix0 - (int)tileX0) | ((uint32_t)(bw - 1) << 8) |
@@ -653,9 +659,9 @@ void bvhTileKernel(const RasterParams p)
                 if (lane == 0)
                     atomicAdd(&ctrl[1], 1u);
             }
-            if (p.debugSkip & 128u) MRX_STAMP(5); else MRX_STAMP(2);
+            if (dskip & 128u) MRX_STAMP(5); else MRX_STAMP(2);
             __syncthreads();
-            if (!(p.debugSkip & 128u)) MRX_STAMP(3);
+            if (!(dskip & 128u)) MRX_STAMP(3);
             // -- the round's large triangles: wave = strip, lane = entry for the box
             //    test, then four pixels of the lane per 32-pixel half.  From here to the
             //    end of the round a wave touches only the pixels of its own strip (the
@@ -736,7 +742,7 @@ void bvhTileKernel(const RasterParams p)
                     }
                 }
             }
-            if (!(p.debugSkip & 128u)) MRX_STAMP(4);
+            if (!(dskip & 128u)) MRX_STAMP(4);
             // -- resolve: every lane looks its eight pixels up; winners whose record
             //    is in the table of this round are shaded now (a later round reuses
             //    the table)
@@ -803,7 +809,7 @@ void bvhTileKernel(const RasterParams p)
                         }
                 }
             }
-            if (!(p.debugSkip & 128u)) MRX_STAMP(5);
+            if (!(dskip & 128u)) MRX_STAMP(5);
             if (allDone)
                 break;                                // (the next pass, if any, opens with a barrier)
             __syncthreads();
@@ -814,7 +820,7 @@ void bvhTileKernel(const RasterParams p)
 
     // ---- output: depth = 1/best (v_rcp_f32, <= 1 ulp), one 16-byte store per
     //      tensor and half
-    if (p.debugSkip & 1u)
+    if (dskip & 1u)
         return;
     const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
     const bool full = (p.nfast & 3u) == 0 && tileX0 + TW <= p.nfast && tileY0 + TH <= p.nslow;

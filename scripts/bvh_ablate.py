@@ -1,5 +1,6 @@
 """Where the BVH kernel's time goes: the same scene with phases switched off
-(MRX_DEBUG_SKIP: 1 stores, 2 pixel tests, 8 triangle setup, 4 traversal)."""
+(MRX_DEBUG_SKIP: 1 stores, 2 pixel tests, 8 triangle setup, 4 traversal).  Needs a library built
+with the kernel's diagnostics:  MRX_EXTRA_HIPCC_FLAGS=-DMRX_BVH_DIAG=1 python -m madrona_renderer_amd.build --force"""
 import os
 import sys
 import time

@@ -1,5 +1,6 @@
 """In-kernel timeline of the BVH kernel (MRX_DEBUG_STAMPS=1): per-phase
-durations of the workgroups, first and second generation."""
+durations of the workgroups, first and second generation.  Needs a library built with the
+kernel's diagnostics:  MRX_EXTRA_HIPCC_FLAGS=-DMRX_BVH_DIAG=1 python -m madrona_renderer_amd.build --force"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MRX_DEBUG_STAMPS"] = "1"

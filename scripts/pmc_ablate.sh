@@ -1,5 +1,6 @@
 #!/bin/bash
 # Dynamic instruction counts of the BVH kernel's phases: SQ counters with phases switched off (MRX_DEBUG_SKIP).
+# Needs a library built with MRX_EXTRA_HIPCC_FLAGS=-DMRX_BVH_DIAG=1 (python -m madrona_renderer_amd.build --force).
 set -u
 export BENCH_ARGS="--cubes 40 --worlds 1024"
 for skip in 0 32 64 96 2 10 14 1; do
