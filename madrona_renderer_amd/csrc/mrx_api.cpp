@@ -528,13 +528,14 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     MRX_HIP(r.triMats.upload(triMats));
     MRX_HIP(r.textures.upload(texDescs));
     MRX_HIP(r.texels.upload(texels));
-    // Which kernel renders: the group kernel (raster.hip) wins on small worlds,
-    // the BVH path (bvh.hip) from about 190 triangles per world on (measured
-    // crossover at 1024 worlds x 64x64: 182 triangles equal, 254 triangles 14 %
-    // ahead, 482 triangles 2x -- profiles/r02_bvh_crossover.txt); it serves both
-    // render modes.  MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3
-    // force the BVH / the raster kernels.
-    uint32_t bvhMinTris = 160;
+    // Which kernel renders: the group kernel (raster.hip) wins while a world fits its
+    // 128-slot instantiation, the BVH path (bvh.hip) as soon as the 256-slot one
+    // would be needed (measured at 1024 worlds x 64x64: 122 triangles 20.9 against
+    // 25.7 us, 134 triangles 28.6 against 27.0, 482 triangles 83 against 31.4 --
+    // profiles/r02_bvh_crossover.txt); it serves both render modes.
+    // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH /
+    // the raster kernels.
+    uint32_t bvhMinTris = 129;
     if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
         bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);

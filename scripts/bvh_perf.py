@@ -37,7 +37,7 @@ def main():
         cases = cases[:2]
     if len(sys.argv) > 1 and sys.argv[1] == "crossover":
         cases = [("1024 x 64^2, %d cubes (%d tris)" % (c, 12 * c + 2), meshes.cube_field(1024, c), 200)
-                 for c in (2, 5, 10, 15, 21, 30, 40)]
+                 for c in ((10, 11, 12, 13, 14) if len(sys.argv) > 2 and sys.argv[2] == "fine" else (2, 5, 10, 15, 21, 30, 40))]
     if len(sys.argv) > 1 and sys.argv[1] == "bvhonly":
         cases = cases[:4] + [("1024 x 64^2, 40 textured cubes", meshes.cube_field(1024, 40, textured=True), 200),
                              ("64 x 256^2 RT, 416 cubes", meshes.cube_field(64, 416, width=256, height=256, mode="Raytracer"), 50),
