@@ -6,27 +6,31 @@
 // (raster.hip), in both render modes: visibility is defined once (DESIGN.md
 // section 3) and this kernel computes the same function of the scene.
 //
-// Wave64 design: the 64 primary rays... are not traced one per lane.  A wave
-// owns a 64x8-pixel strip of a tile (8 pixels per lane, as in the raster
-// kernels) and walks the hierarchy ONCE for the whole strip -- a packet
-// traversal whose control flow is wave-uniform:
-//   TLAS  one lane per instance (64-wide nodes): the instance's object box is
-//         carried to view space and projected; the lanes whose screen
-//         rectangle meets the strip form a ballot mask.  Built per step in LDS
-//         from the live pose tensors (phase I).
+// Wave64 design: the primary rays are not traced one per lane.  One workgroup
+// (one wave per 64x8 strip) owns a tile; its rays are coherent, so the
+// hierarchy is walked ONCE per tile with wave-uniform control flow and the 64
+// lanes are used across the geometry:
+//   TLAS  lane = instance: transform, S6b quantities and the padded screen
+//         rectangle of the bounding sphere of the object's box, in LDS, rebuilt
+//         every step from the live pose tensors (phase I); 64 rectangles are
+//         tested against the tile per instruction.
 //   BLAS  8-wide nodes x 8 box corners = 64 lanes: each lane projects one
 //         corner of one child box, an 8-lane reduction gives the child's
-//         rectangle; hit children go on a per-wave stack in LDS.
+//         rectangle; hit children go on a per-wave stack in LDS.  The waves
+//         share the work by instance / by child of the root.
 //   leaf  candidate triangles are queued and set up 64 at a time (lane =
 //         triangle): the S6 edge / 1-over-depth planes of the spec, exactly as
-//         the raster kernels and the oracle compute them.  The strip's pixels
-//         are then tested against the surviving triangles with the planes
-//         broadcast from LDS (packed FMAs).
+//         the raster kernels and the oracle compute them, once per tile.
+//   pixels  the tile's depth buffer is 64-bit words in LDS merged with
+//         ds_max_u64; small triangles are walked by (triangle, row) items dealt
+//         over the lanes, large ones go on a shared list every wave rasterises
+//         over its own strip after a barrier; winners are shaded from a table
+//         of records in LDS.
 // A box test only ever skips work: rectangles are padded so that no triangle
-// that could own a pixel of the strip is dropped, and the pixel test itself is
-// the spec's.  Traversal order is not draw order, so the winner is chosen by
-// (1/depth, then lower world-local triangle index) -- the total order the
-// oracle's in-order strict '>' scan induces.
+// that could own a pixel is dropped, and the pixel test itself is the spec's.
+// Traversal order is not draw order, so the winner is chosen by (1/depth, then
+// lower world-local triangle index) -- the total order the oracle's in-order
+// strict '>' scan induces.  DESIGN.md section 4.2 has the measurements.
 //
 // Compiled with -ffp-contract=off like raster.hip.
 #include <hip/hip_runtime.h>
