@@ -210,6 +210,7 @@ void bvhTileKernel(const RasterParams p)
     constexpr int kBvhWaves = TH / 8;             // one wave per TW x 8 strip of the tile
     constexpr int kHalves = TW / 32;              // 32-pixel halves of a strip: 4 pixels of a lane each
     constexpr int kCap = tabCap(TEX, TW, TH);
+    constexpr bool kPartial = TEX || CLS;
     constexpr int kBigCap = bigCap(TW, TH);
     static_assert((TW == 64 || TW == 32) && (TH == 64 || TH == 32), "tile shapes of the sweep");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -459,6 +460,11 @@ void bvhTileKernel(const RasterParams p)
                 }
                 if (qCount == 0)
                     break;
+                // (the record table of the round is full already: no point in setting the batch up)
+                if (kPartial && rflu(ctrl[0 + par]) >= (uint32_t)kCap) {
+                    tableFull = true;
+                    break;
+                }
                 waveLdsSync();                        // the queue entries written above are read below
 
                 // -- a batch of up to 64 candidates.  Leaf test setup, lane = triangle:
@@ -516,11 +522,24 @@ void bvhTileKernel(const RasterParams p)
                 if (lane == 0 && numLive)
                     slotBase = atomicAdd(&ctrl[0 + par], numLive);
                 slotBase = rflu(slotBase);
+                // The table fills up in the middle of the batch.  Instantiations whose tables do
+                // overflow in practice (textured: 256 records; CLS: mesh worlds) process the
+                // triangles that still fit and leave the others in the queue for the next round
+                // (kPartial; the round ends for this wave after the batch) -- 100 textured cubes
+                // 101 -> 93 us, mesh worlds 230 -> 218.  The plain untextured kernel, whose 1024
+                // records rarely run out, keeps the shorter code (the extra state costs it 1 %):
+                // it drops the batch and takes it again after the resolve.
+                const uint32_t liveRank = (uint32_t)__builtin_popcountll(liveMask & ((1ull << lane) - 1ull));
+                uint64_t defMask = 0;
                 if (slotBase + numLive > (uint32_t)kCap) {
-                    tableFull = true;                 // wait for the resolve, then take the batch again
-                    break;
+                    tableFull = true;
+                    if (!kPartial)
+                        break;                        // wait for the resolve, then take the batch again
+                    const uint32_t fit = slotBase < (uint32_t)kCap ? (uint32_t)kCap - slotBase : 0u;
+                    defMask = __ballot(live && liveRank >= fit);
+                    live = live && liveRank < fit;
                 }
-                const uint32_t slot = slotBase + (uint32_t)__builtin_popcountll(liveMask & ((1ull << lane) - 1ull));
+                const uint32_t slot = slotBase + liveRank;
                 const uint32_t lowKey = ((~kTri & kKeyMask) << kSlotBits) | slot;
                 if (live) {
                     shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(objL), __uint_as_float(kTri));
@@ -643,17 +662,23 @@ void bvhTileKernel(const RasterParams p)
                     tableFull = true;
                     break;
                 }
-                // -- what did not fit the batch moves to the front of the queue
-                if (qCount > (uint32_t)kWave) {
-                    const uint32_t rem = qCount - kWave;
-                    uint2 e = make_uint2(0u, 0u);
+                // -- what did not fit the batch (or the record table) moves to the front of the queue
+                if (qCount > (uint32_t)kWave || (kPartial && defMask != 0)) {
+                    const uint32_t rem = qCount > (uint32_t)kWave ? qCount - kWave : 0u;
+                    const uint32_t numDef = (uint32_t)__builtin_popcountll(defMask);
+                    const bool deferred = ((defMask >> lane) & 1ull) != 0;
+                    uint2 e = make_uint2(0u, 0u), own = make_uint2(0u, 0u);
                     if ((uint32_t)lane < rem)
                         e = ws->queue[kWave + lane];
+                    if (deferred)
+                        own = ws->queue[lane];
                     waveLdsSync();
+                    if (deferred)
+                        ws->queue[__builtin_popcountll(defMask & ((1ull << lane) - 1ull))] = own;
                     if ((uint32_t)lane < rem)
-                        ws->queue[lane] = e;
+                        ws->queue[numDef + lane] = e;
                     waveLdsSync();
-                    qCount = rem;
+                    qCount = numDef + rem;
                 } else {
                     qCount = 0;
                 }
