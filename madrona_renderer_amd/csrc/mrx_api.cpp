@@ -52,6 +52,10 @@ struct DevBuf {
     size_t count = 0;
     bool owned = true;
     void *base = nullptr;                       // what hipMalloc returned (ptr may sit inside it)
+    // diagnostic (MRX_OUT_ALLOC=vmm): the block comes from the virtual-memory API instead --
+    // one physical handle mapped at a reserved address
+    hipMemGenericAllocationHandle_t vmmHandle {};
+    size_t vmmSize = 0;
     hipError_t alloc(size_t n, size_t tailBytes = 0)     // tail: room for slices (view) behind the data
     {
         count = n;
@@ -59,6 +63,42 @@ struct DevBuf {
         const hipError_t e = hipMalloc(&base, (n ? n : 1) * sizeof(T) + tailBytes);
         ptr = e == hipSuccess ? static_cast<T *>(base) : nullptr;
         return e;
+    }
+    hipError_t allocVmm(size_t n, size_t tailBytes, int device)
+    {
+        count = n;
+        owned = true;
+        hipMemAllocationProp prop {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+        if (e != hipSuccess)
+            return e;
+        if (const char *dbg = std::getenv("MRX_OUT_VMM_GRAN_MB"))
+            gran = std::max<size_t>(gran, (size_t)std::atoll(dbg) << 20);
+        const size_t bytes = ((n ? n : 1) * sizeof(T) + tailBytes + gran - 1) / gran * gran;
+        e = hipMemCreate(&vmmHandle, bytes, &prop, 0);
+        if (e != hipSuccess)
+            return e;
+        e = hipMemAddressReserve(&base, bytes, gran, nullptr, 0);
+        if (e == hipSuccess)
+            e = hipMemMap(base, bytes, 0, vmmHandle, 0);
+        if (e == hipSuccess) {
+            hipMemAccessDesc acc {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(base, bytes, &acc, 1);
+        }
+        if (e != hipSuccess) {
+            (void)hipMemRelease(vmmHandle);
+            base = nullptr;
+            return e;
+        }
+        vmmSize = bytes;
+        ptr = static_cast<T *>(base);
+        return hipSuccess;
     }
     void view(void *base, size_t n)             // a slice of another allocation (not owned)
     {
@@ -76,8 +116,14 @@ struct DevBuf {
     }
     void release()
     {
-        if (base && owned)
+        if (base && owned && vmmSize) {
+            (void)hipMemUnmap(base, vmmSize);
+            (void)hipMemRelease(vmmHandle);
+            (void)hipMemAddressFree(base, vmmSize);
+            vmmSize = 0;
+        } else if (base && owned) {
             (void)hipFree(base);
+        }
         ptr = nullptr;
         base = nullptr;
     }
@@ -147,7 +193,10 @@ hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint
     const size_t depthOff = tb + depthPhase;
     const size_t idsOff = depthOff + tb + kOutPeriod - (depthOff % kOutPeriod) + idsPhase;
     const size_t total = (wantIds ? idsOff : depthOff) + px * 4;
-    const hipError_t e = rgb.alloc(px, total - px * 4);
+    const char *how = std::getenv("MRX_OUT_ALLOC");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const hipError_t e = (how && how[0] == 'v') ? rgb.allocVmm(px, total - px * 4, dev) : rgb.alloc(px, total - px * 4);
     if (e != hipSuccess)
         return e;
     char *base = static_cast<char *>(rgb.base);
