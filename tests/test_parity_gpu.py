@@ -168,6 +168,18 @@ def test_output_placement_search_changes_no_byte_and_pointers_stay_put(native, m
     assert r.rgb_tensor().to_torch().data_ptr() == before[0]
 
 
+def test_outputs_backed_by_the_virtual_memory_api(native, monkeypatch):
+    # MRX_OUT_ALLOC=vmm (a placement diagnostic): one physical handle mapped at a reserved
+    # address; same bytes, and the mapping is torn down with the renderer
+    monkeypatch.setenv("MRX_OUT_ALLOC", "vmm")
+    desc = scenes.synthetic_scene(300, with_wall=True)
+    ref = render_oracle(desc)
+    for _ in range(3):
+        r = make_product(desc, visibility=True)
+        assert_parity(fetch(r), ref)
+        del r
+
+
 def test_headline_config_full_size(native):
     # BASELINE north star: 4096 worlds x 64x64 -- every pixel of every view
     desc = scenes.synthetic_scene(4096)
