@@ -58,3 +58,23 @@ for seed in range(first, first + count):
     if (seed - first) % 20 == 19:
         print("... through seed", seed, "mismatches so far:", bad, flush=True)
 print("soak done, mismatching scenes:", bad, flush=True)
+
+# (3) bench-sized scenes, BVH path against the tiled raster kernels byte for byte (no oracle: it would take minutes)
+import gc
+for name, d in (("1024 x 482", meshes.cube_field(1024, 40)), ("1024 x 1202 RT", meshes.cube_field(1024, 100, mode="Raytracer")),
+                ("256 x 4994 textured", meshes.cube_field(256, 416, textured=True)),
+                ("64 x 14152 meshes 128^2", meshes.mesh_worlds(64, 128, 128)),
+                ("256 x 14152 meshes RT", meshes.mesh_worlds(256, 64, 64, "Raytracer"))):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    rt = d.render_mode == "Raytracer"
+    outs = []
+    for variant in (2, 3):
+        r = make_product(d, visibility=not rt, variant=variant)
+        outs.append(fetch(r, visibility=not rt, raytracer=rt))
+        del r
+        gc.collect()
+    same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+    bad += 0 if same else 1
+    print("bvh == raster on", name, ":", same, flush=True)
+print("soak done incl. differential, mismatching scenes:", bad, flush=True)
