@@ -316,3 +316,28 @@ def test_strip_classification_of_large_triangles_is_exact(native, monkeypatch, c
     ref = render_oracle(d)
     assert_parity(fetch(r), ref)
     assert (ref["tri_id"] >= 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classify", [0, 1])
+def test_quaternions_that_are_not_rotations(native, monkeypatch, classify):
+    # S1 uses quaternions as given: instances and cameras whose quaternion is not of unit length
+    # shear and scale -- box tests, S6b and the leaf test still have to agree with the oracle
+    # (both instantiations of the kernel)
+    monkeypatch.setenv("MRX_BVH_CLASSIFY", str(classify))
+    base = meshes.cube_field(12, 40)
+    inst = []
+    for i, (p_, q_, s_, o_) in enumerate(base.instances):
+        f = (1.0, 1.3, 0.8, 1.00005, 0.6)[i % 5]
+        inst.append((p_, tuple(float(np.float32(c * f)) for c in q_), s_, o_))
+    cams = []
+    for i, (e_, q_) in enumerate(base.cameras):
+        f = (1.0, 0.9, 1.2)[i % 3]
+        cams.append((e_, tuple(float(np.float32(c * f)) for c in q_)))
+    d = scenes.SceneDesc(num_worlds=base.num_worlds, render_mode=base.render_mode, width=64, height=64,
+                         asset_paths=base.asset_paths, materials=base.materials, texture_paths=base.texture_paths,
+                         instances=inst, cameras=cams, worlds=base.worlds)
+    r = make_product(d, visibility=True, variant=2)
+    ref = render_oracle(d)
+    assert_parity(fetch(r), ref)
+    assert (ref["tri_id"] >= 0).mean() > 0.2
