@@ -145,3 +145,22 @@ def test_back_face_rule_is_image_preserving_on_closed_meshes(oracle_mod):
         assert sure.sum() > 100
         assert np.array_equal(ref["tri_id"][v][sure], tri[sure])
         np.testing.assert_allclose(ref["depth"][v][sure], depth[sure], rtol=1e-5)
+
+
+def test_meshes_with_hierarchies_agree_with_float64_moeller_trumbore(oracle_mod):
+    # curved closed meshes (sphere, torus: S6b culls their back faces), an open terrain, a mirrored
+    # instance, cameras on the terrain and inside boxes -- the scenes the BVH path is tested on
+    from tests import meshes
+    d = meshes.mesh_scene_random_cameras(300, 48, 48, "Rasterizer")
+    fs = oracle_mod.FlatScene(d)
+    ref = fs.render()
+    checked = hits = 0
+    for v in (0, 2, 5):
+        tri, depth, margin = raycast_view(fs, v)
+        sure = margin > 1e-5
+        assert np.array_equal(ref["tri_id"][v][sure], tri[sure]), \
+            f"view {v}: {(ref['tri_id'][v][sure] != tri[sure]).sum()} decisive pixels name another triangle"
+        np.testing.assert_allclose(ref["depth"][v][sure], depth[sure], rtol=1e-4)
+        checked += int(sure.sum())
+        hits += int((ref["tri_id"][v] >= 0).sum())
+    assert checked > 0.8 * hits > 0, f"only {checked} of {hits} covered pixels were decisive"
