@@ -162,6 +162,11 @@ def test_meshes_with_hierarchies_agree_with_float64_moeller_trumbore(oracle_mod)
         assert np.array_equal(ref["tri_id"][v][sure], tri[sure]), \
             f"view {v}: {(ref['tri_id'][v][sure] != tri[sure]).sum()} decisive pixels name another triangle"
         np.testing.assert_allclose(ref["depth"][v][sure], depth[sure], rtol=1e-4)
+        # ... and the colours of those pixels follow from the float64 shading model below
+        rgb, sure_tex = raycast_colour(fs, v)
+        near_half = np.abs(rgb - np.floor(rgb) - 0.5) < 0.02
+        diff = np.abs(ref["rgb"][v][..., :3].astype(np.float64) - np.floor(rgb + 0.5))
+        assert not ((sure & sure_tex)[..., None] & (diff > np.where(near_half, 1.0, 0.0))).any()
         checked += int(sure.sum())
         hits += int((ref["tri_id"][v] >= 0).sum())
     assert checked > 0.8 * hits > 0, f"only {checked} of {hits} covered pixels were decisive"
