@@ -814,7 +814,9 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.bvhClassify = blas.nodes.empty() ? 0 : 1;
     if (const char *dbg = std::getenv("MRX_BVH_CLASSIFY"))
         p.bvhClassify = std::atoi(dbg) != 0;
-    p.bvhSmallArea = 32;
+    // (swept on the round's final kernel, 16 ... 4096: a plateau from 192 to 1024 -- only triangles that cover a good
+    // part of the tile are worth the shared list and its barrier; profiles/r02_bvh_perf.txt)
+    p.bvhSmallArea = 256;
     if (const char *dbg = std::getenv("MRX_BVH_SMALL_AREA"))
         p.bvhSmallArea = std::max(0, std::min(4096, std::atoi(dbg)));
     if (const char *dbg = std::getenv("MRX_BVH_PASS_INST"))
