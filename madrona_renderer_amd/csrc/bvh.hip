@@ -274,8 +274,20 @@ void bvhTileKernel(const RasterParams p)
     const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
     const int smallArea = p.bvhSmallArea;
 
-    for (int i = threadIdx.x; i < TW * TH; i += kWave * kBvhWaves)
-        zbuf[i] = packHit(invFar, 0u);
+    {
+        // the waves that have instances to transform in the first pass go straight to their
+        // pose loads: the others clear the depth buffer for them
+        const uint32_t n0 = i1 > i0 ? min(passInst, i1 - i0) : 0u;
+        const uint32_t busy = min((n0 + kWave - 1u) / kWave, (uint32_t)kBvhWaves);
+        if (busy >= (uint32_t)kBvhWaves) {
+            for (int i = threadIdx.x; i < TW * TH; i += kWave * kBvhWaves)
+                zbuf[i] = packHit(invFar, 0u);
+        } else if ((uint32_t)wave >= busy) {
+            for (uint32_t i = ((uint32_t)wave - busy) * kWave + (uint32_t)lane; i < (uint32_t)(TW * TH);
+                 i += ((uint32_t)kBvhWaves - busy) * kWave)
+                zbuf[i] = packHit(invFar, 0u);
+        }
+    }
     if (threadIdx.x == 0)
         ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // records / done waves / large triangles;
                                                                   // [4], [6]: records / large triangles of odd rounds
