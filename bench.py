@@ -6,10 +6,21 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both forms work for N > 1: started plainly (no RANK in the environment),
+``--gpus N`` makes this process a launcher that starts the N ranks itself --
+before it has imported torch or touched HIP -- waits for them and relays rank
+0's line (the reference has a single ``gpuID``, /root/reference/src/mgr.hpp:50;
+one process per GPU is this build's multi-GPU form).  Under
+``torch.distributed.run`` (RANK is set) the process is one of the ranks.
+
 A "step" is one render of every view of the rank's worlds into the contiguous
 [views,H,W,4] RGBA8 + [views,H,W,1] f32 depth tensors; worlds shard across
-ranks with no data-path collective (weak scaling: --worlds per GPU).  Rank 0
-prints ONE JSON line.
+ranks with no data-path collective.  Rank 0 prints ONE JSON line:
+  value / scaling "weak"   --worlds per GPU (default 4096, the north-star shape)
+  also_strong              BASELINE configs[3]: 16384 worlds in total, 16384 / N
+                           per GPU, render-only and with the RCCL all-gather of
+                           the output slabs (sharding.gather_slabs)
+  also                     BASELINE configs[1] (1024 worlds), N = 1 only
 
 Other workloads of BASELINE.json are selected with flags (the default is the
 north-star configuration, 4096 worlds x 64x64 cube+plane):
@@ -22,6 +33,8 @@ north-star configuration, 4096 worlds x 64x64 cube+plane):
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +44,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # untimed renders before the warm-up (clocks leave idle only under load); reported as `settle_s`
 SETTLE_S = float(os.environ.get("MRX_BENCH_SETTLE_S", "0.25"))
+STRONG_WORLDS = 16384    # BASELINE.json configs[3]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
@@ -45,19 +59,85 @@ def parse():
     ap.add_argument("--textured", action="store_true", help="cube textured with cube.png (config C5)")
     ap.add_argument("--mode", default="Rasterizer", choices=["Rasterizer", "Raytracer"])
     ap.add_argument("--cubes", type=int, default=0,
-                    help="many-instance worlds: this many cubes + plane per world (tests/meshes.py)")
+                    help="many-instance worlds: this many cubes + plane per world (scenes.cube_field)")
     ap.add_argument("--variant", type=int, default=0,
                     help="mrx_config.kernel_variant: 0 default dispatch, 2 BVH path, 3 raster kernels")
     ap.add_argument("--first-world", type=int, default=None,
                     help="global id of this rank's first world (default: rank * worlds)")
     ap.add_argument("--gather", action="store_true",
-                    help="also time an RCCL all-gather of the output slabs")
+                    help="also time the headline workload with an RCCL all-gather of the output slabs")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the rank launcher even for --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary 1024-world measurement")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="skip the configs[3] strong-scaling measurement")
+    ap.add_argument("--strong-worlds", type=int, default=STRONG_WORLDS,
+                    help="total worlds of the strong-scaling measurement (configs[3]: 16384)")
     ap.add_argument("--cpu-views", type=int, default=4096)
     ap.add_argument("--cpu-threads", type=int, default=16)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no RANK in the environment
+def launch_ranks(n, argv):
+    """Start N ranks of this script (LOCAL_RANK / RANK / WORLD_SIZE / MASTER_* set),
+    wait for them, relay rank 0's stdout.  This process imports neither torch nor
+    the renderer and makes no HIP call: the ranks are ordinary child processes
+    started before anything here could have initialised a GPU.  A rank that fails
+    ends the job: the others are stopped (by PID) and its code is returned."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MRX_BENCH_LAUNCHER="self")
+        # dmabuf IPC is the only kind the host driver supports (RCCL needs it)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 owns the JSON line; whatever another rank prints goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr,
+                                      text=True if rank == 0 else None))
+    rc = 0
+    out0 = None
+    pending = set(range(n))
+    while pending and rc == 0:
+        for rank in sorted(pending):
+            p = procs[rank]
+            if rank == 0 and out0 is None:
+                # (drain rank 0's pipe while waiting so it can never block on a full pipe)
+                try:
+                    out0, _ = p.communicate(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+            code = p.poll()
+            if code is None:
+                continue
+            pending.discard(rank)
+            if code != 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with code %d" % (rank, code), file=sys.stderr)
+                break
+        if pending and rc == 0:
+            time.sleep(0.05)
+    for rank in pending:                               # a rank failed: stop the ones still running
+        p = procs[rank]
+        if p.poll() is None:
+            p.terminate()
+    for rank in pending:
+        try:
+            procs[rank].wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            procs[rank].kill()
+    # rank 0's JSON line goes to stdout; anything else a library printed there
+    # (gloo announces its connections on stdout) goes to stderr
+    for line in (out0 or "").splitlines():
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    return rc
 
 
 def timed_steps(r, steps, barrier):
@@ -101,17 +181,19 @@ def workload_tag(a, n_gpus):
     return tag
 
 
+def pmc_table():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
 def pmc_traffic(tag):
     """(HBM bytes per launch, where the figure comes from) from the committed
     rocprofv3 --pmc summaries of this same command (profiles/pmc_latest.json),
     or (None, None): the counters are not collected by this run."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)
-    except Exception:
-        return None, None
-    ent = table.get(tag)
+    ent = pmc_table().get(tag)
     if ent is None:
         return None, None
     if isinstance(ent, dict):
@@ -119,20 +201,79 @@ def pmc_traffic(tag):
     return ent, "static: profiles/pmc_latest.json"
 
 
-def make_scene(a, first_world, worlds=None, scenes=None):
+def make_scene(a, first_world, worlds=None, scenes=None, plain=False):
     worlds = a.worlds if worlds is None else worlds
-    if a.cubes:
-        from tests import meshes
-        return meshes.cube_field(worlds, a.cubes, width=a.width, height=a.height, mode=a.mode,
+    if a.cubes and not plain:
+        return scenes.cube_field(worlds, a.cubes, width=a.width, height=a.height, mode=a.mode,
                                  textured=a.textured, first_world=first_world)
+    if plain:       # the BASELINE 64x64 cube+plane shape whatever the flags (configs[1], configs[3])
+        return scenes.synthetic_scene(worlds, first_world=first_world)
     return scenes.synthetic_scene(worlds, width=a.width, height=a.height, with_wall=a.wall,
                                   textured=a.textured, render_mode=a.mode, first_world=first_world)
 
 
-def main():
-    a = parse()
+def settle(r, seconds):
+    """Untimed renders for `seconds` (the card leaves its idle power state only
+    after tens of milliseconds of load; a new renderer's first launches carry the
+    XCC report and cold instruction caches).  Returns the render count."""
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        r.time_renders(100)
+        n += 100
+    return n
+
+
+def bvh_roofline(r, kern_us, views, tiles_per_view):
+    """The BVH kernel is not HBM-bound: its own roofline is the VALU
+    issue rate.  Instruction counts per wave come from the committed SQ-counter summary
+    of the 482-triangle shape (profiles/pmc_latest.json, key "bvh_sq"); the peak is one
+    VALU instruction per cycle per SIMD (MI355X_MICROARCH.md: 4 SIMDs x 256 CUs at
+    2.4 GHz), i.e. 2457.6 G wave-instructions/s."""
+    ent = pmc_table().get("bvh_sq")
+    if not isinstance(ent, dict):
+        return None
+    waves = views * tiles_per_view * 8
+    valu = float(ent.get("valu_per_wave", 0.0)) * waves
+    peak = 256 * 4 * 2.4e9
+    achieved = valu / (kern_us * 1e-6)
+    return {"bound": "valu-issue", "achieved": achieved / 1e9, "peak": peak / 1e9,
+            "unit": "G wave-instr/s", "frac": achieved / peak,
+            "valu_per_wave": ent.get("valu_per_wave"), "source": ent.get("source")}
+
+
+def run_dry(a):
+    """MRX_BENCH_DRY=1: the ranks' control flow without a renderer or a GPU (gloo on
+    CPU tensors) -- process-group init from the launcher's environment, barriers, the
+    MAX reduction of the timing, one line from rank 0.  tests/ use it to exercise the
+    launcher here, where there is no GPU; the numbers mean nothing."""
     import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("MRX_BENCH_DRY_FAIL_RANK") == str(rank):
+        print("rank %d: failing on request" % rank, file=sys.stderr)
+        sys.exit(3)
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     from madrona_renderer_amd import scenes
+    lo, hi = scenes.shard_range(a.strong_worlds, rank, world)
+    cnt = torch.tensor([hi - lo], dtype=torch.int64)
+    dist.all_reduce(cnt)
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": world, "ranks_seen": dist.get_world_size(),
+                          "max_over_ranks": float(t.item()), "strong_worlds_total": int(cnt.item()),
+                          "launcher": os.environ.get("MRX_BENCH_LAUNCHER", "external"),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_rank(a):
+    import torch
+    from madrona_renderer_amd import scenes, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,8 +284,12 @@ def main():
     rehearsal = os.environ.get("MRX_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-    # under torch.distributed.run (RANK is set) the process group is RCCL even
-    # for one rank, so that init, device binding and the collectives run for real
+    elif world > 1 and local >= torch.cuda.device_count():
+        print("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d devices)" % (rank, local, torch.cuda.device_count()),
+              file=sys.stderr)
+        sys.exit(2)
+    # under a launcher (RANK is set) the process group is RCCL even for one
+    # rank, so that init, device binding and the collectives run for real
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -153,14 +298,60 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n_gpus = world if world > 1 else 1
+    ranks_seen = dist.get_world_size() if dist is not None else 1
     if a.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {a.gpus} but WORLD_SIZE={world}; using {n_gpus}",
               file=sys.stderr)
     torch.cuda.set_device(local)
+    coll_dev = "cpu" if rehearsal else "cuda"
 
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_leg(r, steps, views_total):
+        """K steps of render + all-gather of the rank's rgb and depth slabs into the
+        global tensors through sharding.gather_slabs (RCCL all_gather_into_tensor over
+        xGMI; gloo on host copies in a rehearsal)."""
+        rgb = r.rgb_tensor().to_torch()
+        dep = r.depth_tensor().to_torch()
+        if rehearsal:
+            stage = lambda t: t.cpu()
+        else:
+            stage = lambda t: t
+        g_rgb = g_dep = None
+        for _ in range(3):
+            g_rgb = sharding.gather_slabs(stage(rgb), out=g_rgb)
+            g_dep = sharding.gather_slabs(stage(dep), out=g_dep)
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.step()
+            if rehearsal:
+                r.sync()
+            g_rgb = sharding.gather_slabs(stage(rgb), out=g_rgb)
+            g_dep = sharding.gather_slabs(stage(dep), out=g_dep)
+        torch.cuda.synchronize()
+        gw = max_over_ranks(time.perf_counter() - t0)
+        barrier()
+        # the slab of this rank inside the gathered tensor is what it rendered
+        nv = rgb.shape[0]
+        same = bool(torch.equal(g_rgb[rank * nv:(rank + 1) * nv], stage(rgb))) and \
+            bool(torch.equal(g_dep[rank * nv:(rank + 1) * nv], stage(dep)))
+        ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return {"value": views_total * steps / gw, "unit": "views/s", "steps": steps,
+                "ms_per_step": gw * 1000.0 / steps,
+                "collective": "sharding.gather_slabs: all_gather_into_tensor of rgb + depth",
+                "backend": dist.get_backend() if dist is not None else None,
+                "gathered_views": int(g_rgb.shape[0]), "own_slab_intact": bool(ok.item() == 1.0)}
 
     if a.variant:
         os.environ["MADRONA_MI355_KERNEL"] = str(a.variant)
@@ -171,19 +362,12 @@ def main():
     # The card leaves its idle power state only after some tens of milliseconds
     # of load (a 25 us step runs ~10 % slower until then), so the W warm-up
     # steps are preceded by a quarter second of untimed renders (`settle_s`).
-    t_settle = time.perf_counter()
-    settle_renders = 0
-    while time.perf_counter() - t_settle < SETTLE_S:
-        r.time_renders(100)
-        settle_renders += 100
+    settle_renders = settle(r, SETTLE_S)
     for _ in range(a.warmup):
         r.step()
     barrier()                                   # (first use sets the communicator up)
     wall, dev_ms = timed_steps(r, a.steps, barrier)
-    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    wall = max_over_ranks(wall)
     total_views = views * n_gpus
     value = total_views * a.steps / wall
 
@@ -199,6 +383,8 @@ def main():
         "value": value,
         "unit": "views/s",
         "n_gpus": n_gpus,
+        "ranks_seen": ranks_seen,
+        "launcher": os.environ.get("MRX_BENCH_LAUNCHER", "external" if "RANK" in os.environ else "none"),
         "steps": a.steps,
         "warmup": a.warmup,
         "settle_s": SETTLE_S,
@@ -215,7 +401,7 @@ def main():
             "worlds_per_gpu": a.worlds, "views_total": total_views,
             "width": a.width, "height": a.height,
             "kernel_variant": a.variant,
-            "parallelism": "worlds sharded x%d, no collective" % n_gpus,
+            "parallelism": "worlds sharded x%d, no collective (weak: %d worlds on every GPU)" % (n_gpus, a.worlds),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -229,42 +415,31 @@ def main():
             "kernel": "mrx %s (one launch per step)" % r.render_path(),
             "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch,
         },
+        # which output allocation the renderer runs on: outputs of 256 MiB and more come in a
+        # fast and a ~20 % slower mode per allocation (a platform property, profiles/r03_placement.txt);
+        # mrx_create times two candidates and keeps the faster -- this says what it saw
+        "placement": r.placement(),
     }
+    if r.render_path() == "bvh":
+        tiles = ((a.width + 63) // 64) * ((a.height + 63) // 64)
+        own = bvh_roofline(r, kern_us, views, tiles)
+        if own is not None:
+            # the HBM figures stay, as frac_hbm; `frac` is against the bound that applies
+            hb = out["roofline"]
+            own.update({"frac_hbm": hb["frac"], "achieved_hbm_GBps": hb["achieved"], "traffic": hb["traffic"],
+                        "traffic_source": hb["traffic_source"], "kernel": hb["kernel"], "kernel_us": kern_us,
+                        "bytes_per_launch": bytes_per_launch, "frac_wall_hbm": hb["frac_wall"]})
+            out["roofline"] = own
 
     if a.gather and dist is not None:
-        rgb = r.rgb_tensor().to_torch()
-        dep = r.depth_tensor().to_torch()
-        g_rgb = torch.empty((n_gpus,) + tuple(rgb.shape), dtype=rgb.dtype, device="cuda")
-        g_dep = torch.empty((n_gpus,) + tuple(dep.shape), dtype=dep.dtype, device="cuda")
-        for _ in range(3):
-            dist.all_gather_into_tensor(g_rgb, rgb)
-            dist.all_gather_into_tensor(g_dep, dep)
-        barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            r.step()
-            dist.all_gather_into_tensor(g_rgb, rgb)
-            dist.all_gather_into_tensor(g_dep, dep)
-        torch.cuda.synchronize(); barrier()
-        gw = time.perf_counter() - t0
-        # the slab of this rank inside the gathered tensor is what it rendered
-        same = bool(torch.equal(g_rgb[rank], rgb)) and bool(torch.equal(g_dep[rank], dep))
-        out["with_gather"] = {"value": total_views * a.steps / gw, "unit": "views/s",
-                              "ms_per_step": gw * 1000.0 / a.steps,
-                              "collective": "RCCL all_gather_into_tensor rgb+depth",
-                              "backend": dist.get_backend(), "own_slab_intact": same}
+        out["with_gather"] = gather_leg(r, min(a.steps, 500), total_views)
+    del r
 
-    if rank == 0 and n_gpus == 1 and not a.no_extra and a.worlds != 1024:
+    if n_gpus == 1 and not a.no_extra and a.worlds != 1024:
         # BASELINE.json configs[1]: 1024 worlds, same scene, reported beside it
         d2 = make_scene(a, 0, worlds=1024, scenes=scenes)
         r2 = scenes.make_renderer(d2, gpu_id=local)
-        # (a new renderer's first launches carry the XCC report and cold instruction caches:
-        # the same kind of untimed settle as above, 0.1 s, then the W warm-up steps)
-        t_settle = time.perf_counter()
-        settle2 = 0
-        while time.perf_counter() - t_settle < 0.1:
-            r2.time_renders(100)
-            settle2 += 100
+        settle2 = settle(r2, 0.1)
         for _ in range(a.warmup):
             r2.step()
         w2, ms2 = timed_steps(r2, a.steps, lambda: None)
@@ -274,6 +449,32 @@ def main():
                        "kernel_us": ms2 * 1000.0 / a.steps,
                        "settle_s": 0.1, "settle_renders": settle2}
         del r2
+
+    if not a.no_strong:
+        # BASELINE.json configs[3]: 16384 worlds x 64x64 cube+plane IN TOTAL, world-sharded:
+        # rank r renders worlds [lo, hi) of the one job (strong scaling: the driver's
+        # N = 1, 2, 4, 8 values of this entry divide into each other directly), then the
+        # same with the RCCL gather of the output slabs into the global tensors.
+        lo, hi = scenes.shard_range(a.strong_worlds, rank, n_gpus)
+        d3 = make_scene(a, lo, worlds=hi - lo, scenes=scenes, plain=True)
+        r3 = scenes.make_renderer(d3, gpu_id=local)
+        settle3 = settle(r3, 0.1)
+        k3 = min(a.steps, 4000)
+        for _ in range(min(a.warmup, 400)):
+            r3.step()
+        w3, ms3 = timed_steps(r3, k3, barrier)
+        w3 = max_over_ranks(w3)
+        b3 = int(r3.bytes_per_step())
+        strong = {"workload": "%d worlds in total x 64x64 cube+plane (BASELINE configs[3]), %d per GPU"
+                              % (a.strong_worlds, hi - lo),
+                  "scaling": "strong", "value": a.strong_worlds * k3 / w3, "unit": "views/s",
+                  "steps": k3, "ms_per_step": w3 * 1000.0 / k3, "kernel_us": ms3 * 1000.0 / k3,
+                  "frac_kernel": b3 / (ms3 * 1e-3 / k3) / 1e9 / HBM_PEAK_GBPS,
+                  "settle_s": 0.1, "settle_renders": settle3, "placement": r3.placement()}
+        if dist is not None and n_gpus > 1:
+            strong["with_gather"] = gather_leg(r3, min(k3, 200), a.strong_worlds)
+        out["also_strong"] = strong
+        del r3
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         # The reference has no CPU renderer (mgr.cpp:195-197); the baseline is
@@ -298,7 +499,8 @@ def main():
         out["cpu_baseline"] = {
             "value": nv / med, "unit": "views/s", "cores": int(res["threads"]),
             "kind": "port",
-            "sample": "%d views of the same scene per render, %d renders (%.1f s wall, "
+            "sample": "unbinned scalar oracle (every triangle tested at every pixel; the checker, not a "
+                      "tuned CPU renderer): %d views of the same scene per render, %d renders (%.1f s wall, "
                       "%.0f core-seconds), median, OpenMP over views"
                       % (nv, len(times), sum(times), sum(times) * int(res["threads"])),
         }
@@ -307,6 +509,17 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if "RANK" not in os.environ and (a.gpus > 1 or a.spawn):
+        # the launcher: nothing below this line runs in this process
+        sys.exit(launch_ranks(max(1, a.gpus), sys.argv[1:]))
+    if os.environ.get("MRX_BENCH_DRY") == "1":
+        run_dry(a)
+    else:
+        run_rank(a)
 
 
 if __name__ == "__main__":

@@ -97,6 +97,8 @@ public:
     float elapsedMs();                              // event1 - event0, waits for 1
     uint64_t bytesPerStep() const;                  // algorithmic HBM bytes / render
     void *nativeHandle() const;                     // mrx_renderer *
+    // output placement as mrx_placement reports it: candidates timed at creation
+    int placement(float *candUs, int capacity, float *keptUs) const;
     void setStream(void *hipStream);                // launch on this stream from now on
     const char *renderPath() const;                 // "raster" (tiled raster kernels) or "bvh"
 

@@ -207,6 +207,11 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total);
 int64_t mrx_debug_stamps(mrx_renderer *r, uint64_t *dst, int64_t capacity);
 int mrx_mark(mrx_renderer *r, int which);
 int mrx_elapsed_ms(mrx_renderer *r, float *ms);
+/*    Output placement (outputs of 256 MiB and more: mrx_create times at most two
+ *    candidate allocations and keeps the faster): writes the us per
+ *    render of the candidates timed, in order (up to `capacity`), and of the one kept;
+ *    returns how many were timed -- 0 when the layout needed no search. */
+int mrx_placement(mrx_renderer *r, float *cand_us, int capacity, float *kept_us);
 
 /* -- loader cross-check (host copies of what was uploaded) */
 int mrx_copy_triangles(mrx_renderer *r, float *tri_pos /*[T][9]*/,

@@ -187,6 +187,11 @@ uint64_t Manager::bytesPerStep() const
 
 void *Manager::nativeHandle() const { return impl_->r; }
 
+int Manager::placement(float *candUs, int capacity, float *keptUs) const
+{
+    return mrx_placement(impl_->r, candUs, capacity, keptUs);
+}
+
 const char *Manager::renderPath() const
 {
     mrx_info_t info {};

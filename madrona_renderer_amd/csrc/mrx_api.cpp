@@ -243,6 +243,10 @@ struct mrx_renderer {
     DevBuf<mrx::ObjInfo> objInfo;
     bool useBvh = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // what choosePlacement measured (mrx_placement): us per render of every candidate
+    // output allocation it timed, in order, and of the one it kept
+    std::vector<float> placementUs;
+    float placementKeptUs = 0.0f;
 
     hipError_t launch()
     {
@@ -870,9 +874,11 @@ int mrx_device_count(void)
 // after another (alternately all tensors in one block and one block per
 // tensor), each timed with a few renders, and the fastest kept.  Bounded: at
 // most two candidates (the best so far and the current one) plus one small
-// spacer are alive at any time, at most four are tried, and nothing is tried
-// when two more copies of the outputs would not fit a quarter of the free
-// memory.  Outputs below 256 MiB (every 64x64 batch up to 8192 views) are laid
+// spacer are alive at any time, two are tried by default (round 3: a pure
+// two-tensor fill shows the same modes from allocation to allocation --
+// profiles/r03_placement.txt -- so this is a property of the platform, not
+// something a longer search could fix), and nothing is tried when two more
+// copies of the outputs would not fit a quarter of the free memory.  Outputs below 256 MiB (every 64x64 batch up to 8192 views) are laid
 // out deterministically in one block -- depth at phase 256 KiB of the 512 KiB
 // period -- and need no search (what looked like a placement lottery for them
 // in round 1 was the XCD phase of the stream: raster.hip, xcdPhase).
@@ -882,7 +888,7 @@ static int choosePlacement(mrx_renderer *r)
     const size_t px = r->rgb.count;
     const bool wantIds = r->ids.ptr != nullptr;
     const size_t bytes = px * 4 * (wantIds ? 3 : 2);
-    int maxTries = (bytes >= (256ull << 20) && bytes <= (16ull << 30)) ? 4 : 1;
+    int maxTries = (bytes >= (256ull << 20) && bytes <= (16ull << 30)) ? 2 : 1;
     if (const char *dbg = std::getenv("MRX_PLACEMENT_TRIES"))
         maxTries = std::max(1, std::min(16, std::atoi(dbg)));
     if (maxTries > 1) {
@@ -937,6 +943,7 @@ static int choosePlacement(mrx_renderer *r)
     };
     if (st == hipSuccess) st = measure(best);
     float tmax = best.us;
+    r->placementUs.push_back(best.us);
     std::string log;
     char buf[64];
     std::snprintf(buf, sizeof buf, " %.2f", best.us);
@@ -962,6 +969,7 @@ static int choosePlacement(mrx_renderer *r)
         }
         std::snprintf(buf, sizeof buf, " %.2f", c.us);
         log += buf;
+        r->placementUs.push_back(c.us);
         tmax = std::max(tmax, c.us);
         if (c.us < best.us) {
             freeCand(best);
@@ -978,6 +986,7 @@ static int choosePlacement(mrx_renderer *r)
         std::fprintf(stderr, "mrx: output placement, us/render:%s -> %.2f (rgb %p depth %p)\n", log.c_str(),
                      best.us, (void *)best.rgb.ptr, (void *)best.depth.ptr);
     r->rgb = best.rgb; r->depth = best.depth; r->ids = best.ids;
+    r->placementKeptUs = best.us;
     bind(best);
     if (st != hipSuccess)
         return fail(MRX_E_HIP, std::string("output placement: ") + hipGetErrorString(st));
@@ -1238,6 +1247,17 @@ int mrx_elapsed_ms(mrx_renderer *r, float *ms)
     MRX_HIP(hipEventSynchronize(r->ev1));
     MRX_HIP(hipEventElapsedTime(ms, r->ev0, r->ev1));
     return MRX_OK;
+}
+
+int mrx_placement(mrx_renderer *r, float *cand_us, int capacity, float *kept_us)
+{
+    if (!r || (!cand_us && capacity > 0))
+        return fail(MRX_E_INVALID, "bad argument");
+    for (size_t i = 0; i < r->placementUs.size() && (int)i < capacity; ++i)
+        cand_us[i] = r->placementUs[i];
+    if (kept_us)
+        *kept_us = r->placementKeptUs;
+    return (int)r->placementUs.size();
 }
 
 int mrx_copy_triangles(mrx_renderer *r, float *tri_pos, float *tri_uv, int32_t *tri_mat,

@@ -324,6 +324,19 @@ PYBIND11_MODULE(madrona_renderer, m)
         .def("elapsed_ms", &Manager::elapsedMs)
         .def("bytes_per_step", &Manager::bytesPerStep)
         .def("render_path", [](Manager &self) { return std::string(self.renderPath()); })
+        .def("placement",
+             [](Manager &self) {
+                 float us[16] = {}, kept = 0.f;
+                 const int n = self.placement(us, 16, &kept);
+                 py::list cands;
+                 for (int i = 0; i < n && i < 16; ++i)
+                     cands.append(us[i]);
+                 py::dict d;
+                 d["tries"] = n > 0 ? n : 1;
+                 d["candidates_us"] = cands;
+                 d["kept_us"] = n > 0 ? py::object(py::float_(kept)) : py::object(py::none());
+                 return d;
+             })
         .def("native_handle", [](Manager &self) { return (uint64_t)self.nativeHandle(); })
         // e.g. r.set_stream(torch.cuda.current_stream().cuda_stream): pose writes and
         // step() are then ordered on that stream without a host synchronisation

@@ -169,6 +169,36 @@ def synthetic_scene(num_worlds, width=64, height=64, with_wall=False,
                      instances=instances, cameras=cameras, worlds=worlds)
 
 
+def cube_field(num_worlds, cubes, width=64, height=64, mode="Rasterizer", textured=False,
+               seed=1, spread=9.0, first_world=0):
+    """`cubes` cubes scattered over the ground plane of every world (12 * cubes
+    + 2 triangles per world), one camera per world on a ring -- the many-instance
+    shape of worlds the reference's TLAS is for.  Worlds differ (own rows)."""
+    mats = [((0.9, 0.7, 0.5, 1.0), 0 if textured else -1, 0.5, 0.5), ((0.3, 0.6, 0.3, 1.0), -1, 0.5, 0.5)]
+    inst, cams, worlds = [], [], []
+    for w in range(first_world, first_world + num_worlds):
+        rng = np.random.default_rng(seed * 100003 + w)
+        i0 = len(inst)
+        inst.append(((0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 1))
+        for _ in range(cubes):
+            p = rng.uniform(-spread, spread, 2)
+            s = float(rng.uniform(0.4, 1.3))
+            th = float(rng.uniform(0, 2 * math.pi))
+            inst.append(((float(np.float32(p[0])), float(np.float32(p[1])), float(np.float32(0.5 * s))),
+                         tuple(float(np.float32(x)) for x in (math.cos(th / 2), 0, 0, math.sin(th / 2))),
+                         (float(np.float32(s)),) * 3, 0))
+        az = float(rng.uniform(0, 2 * math.pi))
+        r, h = float(rng.uniform(11, 17)), float(rng.uniform(3, 9))
+        eye = tuple(float(np.float32(x)) for x in (r * math.cos(az), r * math.sin(az), h))
+        cams.append((eye, look_at(eye, (0.0, 0.0, 0.5))))
+        worlds.append((cubes + 1, i0, 1, len(cams) - 1))
+    return SceneDesc(
+        num_worlds=num_worlds, render_mode=mode, width=width, height=height,
+        asset_paths=[(os.path.join(DATA_DIR, "cube.obj"), 0), (os.path.join(DATA_DIR, "plane.obj"), 1)], materials=mats,
+        texture_paths=[os.path.join(DATA_DIR, "cube.png")],
+        instances=inst, cameras=cams, worlds=worlds)
+
+
 def demo_scene(num_worlds=4, render_mode="Raytracer", width=64, height=64,
                data_dir=None):
     """The literal scene of /root/reference/scripts/test.py:11-130: cube.obj +

@@ -22,25 +22,31 @@ def view_ranges(worlds, world_size):
     return out
 
 
-def gather_slabs(local, counts=None, group=None):
+def gather_slabs(local, counts=None, group=None, out=None):
     """All-gather per-rank output slabs along dim 0 into the global tensor.
 
     ``local``  this rank's [views_r, ...] tensor (device tensor under nccl,
                CPU tensor under gloo);
     ``counts`` views per rank when they differ (ragged shards are padded to the
-               largest slab so the exchange stays one fused collective).
+               largest slab so the exchange stays one fused collective);
+    ``out``    a [world_size * max(views_r), ...] tensor of a previous call to
+               receive into again (a per-step gather allocates nothing).
     World size 1 is a no-op that returns ``local`` itself."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     if ws == 1:
         return local
     if counts is None or len(set(counts)) == 1:
-        out = local.new_empty((ws * local.shape[0],) + tuple(local.shape[1:]))
+        shape = (ws * local.shape[0],) + tuple(local.shape[1:])
+        if out is None or tuple(out.shape) != shape:
+            out = local.new_empty(shape)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
     # ragged shards: pad every slab to the largest, one fused collective, trim
     top = max(counts)
     padded = local.new_zeros((top,) + tuple(local.shape[1:]))
     padded[:local.shape[0]] = local
-    out = local.new_empty((ws * top,) + tuple(local.shape[1:]))
+    shape = (ws * top,) + tuple(local.shape[1:])
+    if out is None or tuple(out.shape) != shape:
+        out = local.new_empty(shape)
     dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * top:r * top + c] for r, c in enumerate(counts)], dim=0)

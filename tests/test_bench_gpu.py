@@ -15,7 +15,7 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_keys(native):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "30",
-                        "--worlds", "512", "--cpu-views", "256", "--no-extra"],
+                        "--worlds", "512", "--cpu-views", "256", "--no-extra", "--strong-worlds", "2048"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -38,6 +38,13 @@ def test_bench_line_has_the_contract_keys(native):
     assert abs(out["value"] - 512 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "views/s"
+    assert "unbinned scalar oracle" in c["sample"]
+    assert out["ranks_seen"] == 1 and out["launcher"] == "none"
+    # outputs below 256 MiB are laid out deterministically: no candidates were timed
+    assert out["placement"] == {"tries": 1, "candidates_us": [], "kept_us": None}
+    st = out["also_strong"]
+    assert st["scaling"] == "strong" and st["unit"] == "views/s" and "with_gather" not in st
+    assert abs(st["value"] - 2048 / (st["ms_per_step"] * 1e-3)) / st["value"] < 1e-6
 
 
 @pytest.mark.gpu
@@ -54,7 +61,7 @@ def test_bench_under_torchrun_runs_rccl_for_real(native):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "100", "--warmup", "10",
-                        "--worlds", "256", "--gather", "--no-cpu-baseline", "--no-extra"],
+                        "--worlds", "256", "--gather", "--no-cpu-baseline", "--no-extra", "--no-strong"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -63,12 +70,57 @@ def test_bench_under_torchrun_runs_rccl_for_real(native):
     assert g["backend"] == "nccl" and g["own_slab_intact"] is True and g["value"] > 0
     assert out["n_gpus"] == 1 and out["roofline"]["traffic"] is None
     assert out["roofline"]["traffic_source"] is None
+    assert out["ranks_seen"] == 1 and out["launcher"] == "external"
+
+
+@pytest.mark.gpu
+def test_bench_through_its_own_launcher_one_rank_rccl(native):
+    # `bench.py --gpus N` started plainly starts the ranks itself.  One
+    # rank through that same path (--spawn): the child gets RANK / LOCAL_RANK / MASTER_*
+    # from the launcher and brings the RCCL group up with device binding.
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "100",
+                        "--warmup", "10", "--worlds", "256", "--gather", "--no-cpu-baseline", "--no-extra",
+                        "--strong-worlds", "1024"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["launcher"] == "self" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
+    assert out["with_gather"]["backend"] == "nccl" and out["with_gather"]["own_slab_intact"] is True
+    assert out["also_strong"]["scaling"] == "strong" and out["also_strong"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_rehearsed_on_one_gpu(native):
+    # Two ranks started by bench.py itself, both on cuda:0 (MRX_BENCH_REHEARSAL=1: gloo for
+    # the collectives, the numbers mean nothing): the N > 1 control flow end to end --
+    # world shards by rank, MAX over ranks, the configs[3] strong leg with 16384 / N worlds per
+    # rank and its gather through sharding.gather_slabs.
+    env = dict(os.environ, MRX_BENCH_REHEARSAL="1")
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100",
+                        "--warmup", "10", "--worlds", "256", "--strong-worlds", "1024"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["launcher"] == "self"
+    assert out["config"]["views_total"] == 512 and out["scaling"] == "weak"
+    st = out["also_strong"]
+    assert "512 per GPU" in st["workload"] and st["scaling"] == "strong"
+    g = st["with_gather"]
+    assert g["gathered_views"] == 1024 and g["own_slab_intact"] is True and g["backend"] == "gloo"
+    assert "cpu_baseline" not in out and "also" not in out
 
 
 @pytest.mark.gpu
 def test_bench_line_on_the_bvh_path(native):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5",
-                        "--worlds", "128", "--cubes", "40", "--no-cpu-baseline", "--no-extra"],
+                        "--worlds", "128", "--cubes", "40", "--no-cpu-baseline", "--no-extra", "--no-strong"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
