@@ -116,8 +116,8 @@ typedef struct {
     /* build-only knobs (no counterpart in the reference) */
     void *stream;               /* hipStream_t to launch on; NULL = null stream */
     uint32_t flags;             /* MRX_FLAG_* */
-    int32_t kernel_variant;     /* 0 = default (raster kernels up to 256 triangles per
-                                 * world, BVH path above); 1 = brute-force cross-check;
+    int32_t kernel_variant;     /* 0 = default (raster kernels up to 128 triangles per
+                                 * world, BVH path from 129); 1 = brute-force cross-check;
                                  * 2 = BVH path always; 3 = raster kernels always */
 } mrx_config;
 
@@ -140,7 +140,9 @@ enum {
      * from the next step on (cleanupRenderableEntity, src/sim.inl:10-16), writing
      * the id back shows it again (makeEntityRenderable, src/sim.inl:5-8).  Only
      * the sign is interpreted: the geometry an instance draws is bound when the
-     * renderer is created, and triangle slots / visibility ids stay where they are. */
+     * renderer is created, triangle slots / visibility ids stay where they are, and
+     * the segmask shows the id of the bound object (label and geometry always agree:
+     * writing a different non-negative id changes neither). */
     MRX_BUF_INSTANCE_OBJECT = 9,
     MRX_NUM_BUFFERS = 10
 };
@@ -221,9 +223,12 @@ int mrx_copy_triangles(mrx_renderer *r, float *tri_pos /*[T][9]*/,
 /* -- host-only asset readers (no device needed); free results with mrx_free */
 int mrx_load_obj(const char *path, float **tri_pos, float **tri_uv,
                  uint32_t *num_tris);
-/*    The objects of an OBJ file (one per `o` / `g` block with faces,
- *    /root/reference/src/mgr.cpp:294-307): writes up to `capacity` first-triangle
- *    indices and returns the object count, or a negative MRX_E_*. */
+/*    The `o` / `g` blocks (with faces) of an OBJ file: writes up to `capacity`
+ *    first-triangle indices and returns the block count, or a negative MRX_E_*.
+ *    mrx_create makes ONE object of an asset file, as the reference does
+ *    (importFromDisk(..., one_object_per_asset = true), /root/reference/src/mgr.cpp:301-303;
+ *    objects[i] <-> asset path i, :340-345) -- the blocks are its meshes; with
+ *    MRX_OBJ_SPLIT_BLOCKS=1 in the environment every block becomes an object of its own. */
 int mrx_obj_objects(const char *path, uint32_t *first_tri, uint32_t capacity);
 int mrx_decode_png(const char *path, uint8_t **rgba, uint32_t *width,
                    uint32_t *height);

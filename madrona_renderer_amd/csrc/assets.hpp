@@ -10,15 +10,16 @@
 
 namespace mrx {
 
-// Object-space triangle soup of one OBJ file.  A file holds one object per
-// `o` / `g` block that has faces (faces ahead of the first statement form an
-// object of their own), the way the reference's importer hands back
-// ImportedAssets::objects (/root/reference/src/mgr.cpp:294-307); objStart lists
-// the first triangle of each.
+// Object-space triangle soup of one OBJ file.  objStart lists the first triangle
+// of each `o` / `g` block that has faces (faces ahead of the first statement form a
+// block of their own).  mrx_create makes one object of the whole file, like the
+// reference (importFromDisk(..., one_object_per_asset = true),
+// /root/reference/src/mgr.cpp:301-303; objects[i] <-> asset path i, :340-345); the
+// blocks only become objects of their own under MRX_OBJ_SPLIT_BLOCKS=1.
 struct TriSoup {
     std::vector<float> pos;  // [T][3 verts][xyz]
     std::vector<float> uv;   // [T][3 verts][uv]
-    std::vector<uint32_t> objStart;   // first triangle of each object, ascending; at least one entry
+    std::vector<uint32_t> objStart;   // first triangle of each block, ascending; at least one entry
     // `usemtl` of each triangle as an index into mtlNames, -1 = none
     std::vector<int32_t> triMtl;
     std::vector<std::string> mtlNames;

@@ -54,7 +54,11 @@ struct Builder {
     std::vector<BinNode> bin;
     bool median = false;
 
-    int32_t build(uint32_t first, uint32_t count)
+    // SAH splits can be arbitrarily lopsided (a few primitives peeled off per level on
+    // adversarial meshes): beyond kSahDepth levels the subtree is built with median splits,
+    // which halve the range, so the recursion depth is bounded by kSahDepth + log2(count)
+    static constexpr uint32_t kSahDepth = 48;
+    int32_t build(uint32_t first, uint32_t count, uint32_t level = 0)
     {
         BinNode n;
         n.first = first;
@@ -78,7 +82,7 @@ struct Builder {
             }
         uint32_t mid = first + count / 2;
         bool split = false;
-        if (!median && ext > 0.0f) {
+        if (!median && level < kSahDepth && ext > 0.0f) {
             constexpr int kBins = 16;
             double bestCost = DBL_MAX;
             int bestAxis = -1, bestBin = -1;
@@ -138,8 +142,8 @@ struct Builder {
             std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
                              [&](const Prim &a, const Prim &b) { return a.c[axis] < b.c[axis]; });
         }
-        const int32_t l = build(first, mid - first);
-        const int32_t r = build(mid, first + count - mid);
+        const int32_t l = build(first, mid - first, level + 1);
+        const int32_t r = build(mid, first + count - mid, level + 1);
         bin[me].left = l;
         bin[me].right = r;
         return me;
@@ -147,7 +151,10 @@ struct Builder {
 };
 
 // Collapse binary node `b` into an 8-wide node; returns its index in out.nodes.
-uint32_t collapse(const Builder &bl, int32_t b, BlasSet &out, uint32_t depth, uint32_t &maxDepth)
+// `balanced`: open the child with the most primitives instead of the largest area -- over a
+// median-split tree that gives wide nodes of near-equal subtrees, i.e. a depth of about a third
+// of the binary tree's (the largest-area rule carries no such guarantee).
+uint32_t collapse(const Builder &bl, int32_t b, BlasSet &out, uint32_t depth, uint32_t &maxDepth, bool balanced)
 {
     maxDepth = std::max(maxDepth, depth);
     std::vector<int32_t> kids = { bl.bin[b].left, bl.bin[b].right };
@@ -157,8 +164,9 @@ uint32_t collapse(const Builder &bl, int32_t b, BlasSet &out, uint32_t depth, ui
         double bestArea = -1.0;
         for (size_t i = 0; i < kids.size(); ++i) {
             const BinNode &k = bl.bin[kids[i]];
-            if (k.left >= 0 && k.box.area() > bestArea) {
-                bestArea = k.box.area();
+            const double key = balanced ? (double)k.count : k.box.area();
+            if (k.left >= 0 && key > bestArea) {
+                bestArea = key;
                 best = (int)i;
             }
         }
@@ -185,7 +193,7 @@ uint32_t collapse(const Builder &bl, int32_t b, BlasSet &out, uint32_t depth, ui
                 out.leafTris.push_back(bl.prims[k.first + i].tri);
             ref = kBvhLeafBit | ((k.count - 1) << kBvhLeafStartBits) | start;
         } else {
-            ref = collapse(bl, kids[c], out, depth + 1, maxDepth);
+            ref = collapse(bl, kids[c], out, depth + 1, maxDepth, balanced);
         }
         BvhNode &n = out.nodes[me];      // (re-fetch: the vector may have grown)
         std::memcpy(n.bmin[c], k.box.lo, 12);
@@ -233,8 +241,10 @@ void buildBlas(const ObjTri *tris, const std::vector<int32_t> &objFirst,
                 const int32_t rootBin = bl.build(0, count);
                 const size_t nodes0 = out.nodes.size(), leaves0 = out.leafTris.size();
                 uint32_t depth = 0;
-                const uint32_t root = collapse(bl, rootBin, out, 1, depth);
-                // a pop pushes at most eight entries: 1 + 7 per level bounds the stack
+                const uint32_t root = collapse(bl, rootBin, out, 1, depth, attempt == 1);
+                // a pop pushes at most eight entries: 1 + 7 per level bounds the stack.  The
+                // balanced rebuild is accepted as it comes: buildScene (mrx_api.cpp) refuses a
+                // scene whose deepest BLAS still exceeds the bound
                 if (1 + 7 * depth <= kBvhStackCap || attempt == 1) {
                     info.root = (int32_t)root;
                     out.maxDepth = std::max(out.maxDepth, depth);

@@ -35,6 +35,7 @@
 // Compiled with -ffp-contract=off like raster.hip.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
 
 #include "bvh.hpp"
 #include "raster_dev.hpp"
@@ -554,7 +555,7 @@ void bvhTileKernel(const RasterParams p)
                 const uint32_t slot = slotBase + liveRank;
                 const uint32_t lowKey = ((~kTri & kKeyMask) << kSlotBits) | slot;
                 if (live) {
-                    shadeTab[slot] = make_float4(shade[0], shade[1], __int_as_float(objL), __uint_as_float(kTri));
+                    shadeTab[slot] = make_float4(shade[0], shade[1], shade[2], __uint_as_float(kTri));   // [2]: the triangle's object id
                     if (TEX && __float_as_int(shade[1]) >= 0) {
 #pragma unroll
                         for (int i = 0; i < 9; ++i)
@@ -902,6 +903,8 @@ void bvhTileKernel(const RasterParams p)
 }  // namespace
 
 namespace {
+constexpr int kMaxDevices = 64;
+std::mutex attrMutex;
 // LDS bytes of one workgroup for a tile shape
 size_t ldsFor(uint32_t passInst, bool textured, int tw, int th)
 {
@@ -924,15 +927,31 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     const uint32_t items = p.numViews * ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
     const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th);
     const dim3 grid(items), block(kWave * (th / 8));
+    // The kernel needs more dynamic LDS than the 64 KB a launch may ask for by default.  The
+    // opt-in is a property of (function, device) -- a renderer per device in one process
+    // (mrx_config.device_ids, renderer_headless --gpus N) launches the same instantiation on
+    // several devices, from several host threads -- so what has been granted is remembered
+    // per device, under a lock.
+    int dev = 0;
+    {
+        const hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess)
+            return e;
+        if (dev < 0 || dev >= kMaxDevices)
+            return hipErrorInvalidDevice;
+    }
 #define MRX_BVH(I, T, W, H, C)                                                                 \
     do {                                                                                       \
-        static size_t allowed = 0;                                                             \
-        if (lds > allowed) {                                                                   \
-            const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H, C>, \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess)                                                               \
-                return e;                                                                      \
-            allowed = lds;                                                                     \
+        static size_t allowed[kMaxDevices] = {};                                               \
+        {                                                                                      \
+            std::lock_guard<std::mutex> guard(attrMutex);                                      \
+            if (lds > allowed[dev]) {                                                          \
+                const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H, C>, \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess)                                                           \
+                    return e;                                                                  \
+                allowed[dev] = lds;                                                            \
+            }                                                                                  \
         }                                                                                      \
         bvhTileKernel<I, T, W, H, C><<<grid, block, lds, stream>>>(p);                         \
     } while (0)

@@ -407,11 +407,20 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         int32_t mat = -1;
         if (cfg.mat_assignments && a < cfg.num_mat_assignments)
             mat = cfg.mat_assignments[a];
-        // one object per `o` / `g` block of the file (mgr.cpp:294-307: objects, plural)
-        for (size_t o = 0; o < soup.objStart.size(); ++o) {
-            const uint32_t t0 = soup.objStart[o];
-            const uint32_t t1 = o + 1 < soup.objStart.size() ? soup.objStart[o + 1] : soup.numTris();
-            appendObject(soup.pos.data() + 9 * (size_t)t0, soup.uv.data() + 6 * (size_t)t0, t1 - t0, mat);
+        // One object per asset FILE: the reference imports with one_object_per_asset
+        // (the `true` of importFromDisk, mgr.cpp:301-303) and addresses objects[i] by asset
+        // path i (mgr.cpp:340-345), so the `o` / `g` blocks of a file are the meshes of one
+        // object and later assets / raw meshes keep the ids the reference gives them.
+        // MRX_OBJ_SPLIT_BLOCKS=1 opts into one object per block instead.
+        const char *split = std::getenv("MRX_OBJ_SPLIT_BLOCKS");
+        if (split && split[0] == '1') {
+            for (size_t o = 0; o < soup.objStart.size(); ++o) {
+                const uint32_t t0 = soup.objStart[o];
+                const uint32_t t1 = o + 1 < soup.objStart.size() ? soup.objStart[o + 1] : soup.numTris();
+                appendObject(soup.pos.data() + 9 * (size_t)t0, soup.uv.data() + 6 * (size_t)t0, t1 - t0, mat);
+            }
+        } else {
+            appendObject(soup.pos.data(), soup.uv.data(), soup.numTris(), mat);
         }
         if (mat < 0 && !soup.mtlNames.empty()) {
             std::vector<MtlMaterial> lib;
@@ -528,6 +537,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             tm.texDesc[2] = (int32_t)texDescs[tm.tex].height;
         }
     }
+    // the object a triangle belongs to rides in the alpha slot (segmask label, raster.hpp)
+    for (size_t o = 0; o < r.objFirst.size(); ++o)
+        for (int32_t t = 0; t < r.objCount[o]; ++t) {
+            const int32_t id = (int32_t)o;
+            std::memcpy(&triMats[(size_t)r.objFirst[o] + t].color[3], &id, 4);
+        }
     // S6b: orientation and padded bounding box of every triangle's shell
     for (size_t o = 0; o < r.objFirst.size(); ++o)
         shellOrientation(tris.data() + r.objFirst[o], (uint32_t)r.objCount[o],
@@ -588,7 +603,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     // profiles/r02_bvh_crossover.txt); it serves both render modes.
     // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH /
     // the raster kernels.
-    uint32_t bvhMinTris = 129;
+    uint32_t bvhMinTris = kBvhMinTris;
     if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
         bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);
@@ -615,6 +630,12 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     buildBlas(tris.data(), r.objFirst, r.objCount, blas);
     if (blas.leafTris.size() >= (1u << kBvhLeafStartBits))
         return fail(MRX_E_UNSUPPORTED, "too many triangles in BLAS leaves");
+    // (the kernel's traversal stack is kBvhStackCap entries of LDS per wave: a deeper tree
+    // would write past it -- bvh.cpp rebuilds such trees balanced, which bounds the depth
+    // by about log8 of the triangle count; refuse what still does not fit)
+    if (1 + 7 * blas.maxDepth > kBvhStackCap)
+        return fail(MRX_E_UNSUPPORTED, "a BLAS is too deep for the traversal stack (" +
+                                           std::to_string(blas.maxDepth) + " levels)");
     // per instance: range, root and box of its (creation-time) object, so the
     // per-step TLAS build has no load that depends on another
     std::vector<ObjInfo> instInfo(instObj.size());

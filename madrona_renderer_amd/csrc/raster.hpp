@@ -21,6 +21,9 @@ static_assert(sizeof(ObjTri) == 64, "ObjTri must be one 64-byte line");
 // Material of one object triangle, resolved on the host (mesh material or the
 // default colour; texture index validated): one 32-byte record next to ObjTri.
 struct alignas(16) TriMat {
+    // rgb of the resolved material; the alpha slot (nothing shades with it) holds the
+    // int32 id of the object the triangle belongs to -- the segmask label, so that label
+    // and geometry agree whatever non-negative value the live ObjectID column holds
     float color[4];
     int32_t tex;       // texture index, -1 = untextured
     // S6b back-face culling data of the triangle's shell (edge-connected
@@ -139,6 +142,10 @@ struct RasterParams {
     int32_t bvhSmallArea;            // boxes of up to this many pixels are walked by their triangle's lane
     int32_t bvhClassify;             // 64x64 tiles: the instantiation that classifies listed triangles per strip
 };
+
+// Default dispatch: worlds of this many triangles and more take the BVH path
+// (measured crossover, profiles/r02_bvh_crossover.txt; MRX_BVH_MIN_TRIS overrides).
+constexpr uint32_t kBvhMinTris = 129;
 
 // Kernel variants (mrx_config.kernel_variant).
 enum KernelVariant : int32_t {

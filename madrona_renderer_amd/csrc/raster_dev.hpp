@@ -240,7 +240,7 @@ __device__ __forceinline__ bool setupTriangleCore(const RasterParams &p, const f
     const uint32_t rgba = toU8(l0) | (toU8(l1) << 8) | (toU8(l2) << 16) | 0xFF000000u;
     shade[0] = __uint_as_float(rgba);
     shade[1] = __int_as_float(tex);
-    shade[2] = __int_as_float(obj);
+    shade[2] = obj >= 0 ? mc.w : __int_as_float(obj);   // the triangle's own object id (TriMat alpha slot)
     shade[3] = __int_as_float(kWorld);
     return valid;
 }

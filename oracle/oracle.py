@@ -106,8 +106,9 @@ def parse_obj(path, with_materials=False, with_objects=False):
     Polygons fan-triangulated; ``vt`` optional.  With ``with_materials`` also
     returns (tri_mtl [T] index into names or -1, names, mtllib paths resolved
     against the OBJ's directory); with ``with_objects`` the first triangle of
-    each object last -- one object per ``o`` / ``g`` block that holds faces
-    (/root/reference/src/mgr.cpp:294-307 receives ImportedAssets::objects)."""
+    each ``o`` / ``g`` block that holds faces last (FlatScene makes one object of
+    a file, as /root/reference/src/mgr.cpp:301-303,340-345 does, unless
+    MRX_OBJ_SPLIT_BLOCKS=1)."""
     vs, vts, tris_p, tris_t = [], [], [], []
     tri_mtl, names, libs, cur = [], [], [], -1
     obj_start = [0]
@@ -358,7 +359,12 @@ class FlatScene:
                     if k >= 0:
                         tm[i] = name_to_mat[k]
             mat_l.append(tm)
-            for o, t0 in enumerate(starts):       # one object per `o` / `g` block
+            # one object per asset file (importFromDisk(..., true) and objects[i] <-> asset i,
+            # mgr.cpp:301-303,340-345): `o` / `g` blocks are meshes of the one object;
+            # MRX_OBJ_SPLIT_BLOCKS=1 opts into one object per block
+            if os.environ.get("MRX_OBJ_SPLIT_BLOCKS", "")[:1] != "1":
+                starts = [0]
+            for o, t0 in enumerate(starts):
                 t1 = starts[o + 1] if o + 1 < len(starts) else len(p)
                 first.append(ntri + t0)
                 count.append(t1 - t0)

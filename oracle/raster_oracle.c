@@ -252,7 +252,7 @@ static int setup_view(const orc_scene *s, int v, orc_tri *out)
             o->rgba = to_u8(o->lit[0]) | (to_u8(o->lit[1]) << 8) |
                       (to_u8(o->lit[2]) << 16) | 0xFF000000u;
             o->tex = tex;
-            o->seg = s->inst_obj[i];
+            o->seg = obj;                         /* the bound object: label and geometry always agree */
             o->k = k;
         }
     }

@@ -269,9 +269,10 @@ f 1 2 3
 """
 
 
-def test_obj_files_yield_one_object_per_block(native, oracle_mod, tmp_path):
-    # /root/reference/src/mgr.cpp:294-307: importFromDisk hands back objects
-    # (plural) per file; here one per `o` / `g` block that holds faces
+def test_obj_file_is_one_object_and_blocks_split_on_request(native, oracle_mod, tmp_path, monkeypatch):
+    # /root/reference/src/mgr.cpp:301-303,340-345: importFromDisk(..., one_object_per_asset)
+    # and objects[i] <-> asset path i -- a file is one object whatever blocks it holds
+    # (ADVICE r2); MRX_OBJ_SPLIT_BLOCKS=1 makes one object per `o` / `g` block with faces
     path = tmp_path / "multi.obj"
     path.write_text(MULTI_OBJ)
     lib = native.load_capi()
@@ -284,7 +285,7 @@ def test_obj_files_yield_one_object_per_block(native, oracle_mod, tmp_path):
     assert rc == 0 and np.array_equal(cpos, pos)
     # the files of data/ hold one block each
     assert lib.mrx_obj_objects(os.path.join(scenes.DATA_DIR, "cube.obj").encode(), first, 8) == 1
-    # in a scene: the file's objects take ids 0..2, the next asset id 3, the raw mesh id 4
+    # in a scene: the file is object 0, the next asset 1, the raw mesh 2 ...
     d = scenes.SceneDesc(
         num_worlds=1, asset_paths=[(str(path), -1), (os.path.join(scenes.DATA_DIR, "plane.obj"), -1)],
         mesh_vertices=np.zeros((3, 3), np.float32), mesh_uvs=np.zeros((3, 2), np.float32),
@@ -292,5 +293,10 @@ def test_obj_files_yield_one_object_per_block(native, oracle_mod, tmp_path):
         mesh_indices_offsets=np.zeros(1, np.uint32), mesh_materials=np.array([-1], np.int32),
         instances=[((0.0, 3.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 2)],
         cameras=[((0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0))], worlds=[(1, 0, 1, 0)])
+    monkeypatch.delenv("MRX_OBJ_SPLIT_BLOCKS", raising=False)
+    fs = oracle_mod.FlatScene(d)
+    assert fs.obj_first_tri.tolist() == [0, 7, 9] and fs.obj_num_tris.tolist() == [7, 2, 1]
+    # ... on request the file's blocks take ids 0..2, the next asset id 3, the raw mesh id 4
+    monkeypatch.setenv("MRX_OBJ_SPLIT_BLOCKS", "1")
     fs = oracle_mod.FlatScene(d)
     assert fs.obj_first_tri.tolist() == [0, 2, 5, 7, 9] and fs.obj_num_tris.tolist() == [2, 3, 2, 2, 1]

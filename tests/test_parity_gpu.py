@@ -487,13 +487,20 @@ def test_obj_materials_from_mtl(native, tmp_path):
     assert len(colours) > 10                      # textured faces show many texel colours
 
 
-def test_multi_object_obj_numbers_objects_per_block(native, tmp_path):
-    # one object per `o` / `g` block (mgr.cpp:294-307): instances address them by
-    # id, later assets and raw meshes are numbered after them
+@pytest.mark.parametrize("split", [False, True])
+def test_multi_block_obj_is_one_object_unless_split(native, tmp_path, monkeypatch, split):
+    # An OBJ file is one object whatever `o` / `g` blocks it holds (importFromDisk(..., true),
+    # objects[i] <-> asset i: mgr.cpp:301-303,340-345): the next asset is object 1.  With
+    # MRX_OBJ_SPLIT_BLOCKS=1 the three blocks are objects 0..2 and the next asset is object 3.
     from tests.test_host_logic import MULTI_OBJ
     path = tmp_path / "multi.obj"
     path.write_text(MULTI_OBJ)
+    if split:
+        monkeypatch.setenv("MRX_OBJ_SPLIT_BLOCKS", "1")
+    else:
+        monkeypatch.delenv("MRX_OBJ_SPLIT_BLOCKS", raising=False)
     q = (0.7071068, 0.7071068, 0.0, 0.0)
+    cube_id = 3 if split else 1
     for mode in ("Rasterizer", "Raytracer"):
         d = scenes.SceneDesc(
             num_worlds=2, width=64, height=64, render_mode=mode,
@@ -507,8 +514,13 @@ def test_multi_object_obj_numbers_objects_per_block(native, tmp_path):
         got = fetch(r, visibility=False, raytracer=(mode == "Raytracer"))
         ref = render_oracle(d)
         assert_parity(got, ref)
+        from oracle import oracle
+        fs = oracle.FlatScene(d)
+        assert fs.obj_num_tris.tolist() == ([2, 3, 2, 12] if split else [7, 12])
+        assert int(fs.obj_num_tris[cube_id]) == 12
         if mode == "Raytracer":
-            assert set(np.unique(ref["segmask"][0]).tolist()) == {-1, 0, 1, 2, 3}
+            # (objects that do not exist draw nothing: ids 2.. unsplit, id 4 split)
+            assert set(np.unique(ref["segmask"][0]).tolist()) == ({-1, 0, 1, 2, 3} if split else {-1, 0, 1})
 
 
 @pytest.mark.parametrize("kind", ["uniform", "ragged", "bvh"])
@@ -544,6 +556,31 @@ def test_instances_hidden_and_shown_between_steps(native, kind):
         first = ref if first is None else first
         assert step == 3 or not np.array_equal(ref["tri_id"], full_ids(fs))
     assert np.array_equal(got["tri_id"], full_ids(fs))
+
+
+@pytest.mark.parametrize("kind", ["raster", "bvh"])
+def test_a_different_nonnegative_object_id_changes_neither_geometry_nor_segmask(native, kind):
+    # the geometry of an instance is bound at creation; only the sign of the live
+    # ObjectID is interpreted.  The segmask therefore shows the id of the BOUND object, so
+    # that labels and geometry agree whatever non-negative value the column holds.
+    import torch
+    from tests import meshes
+    if kind == "raster":
+        d = scenes.synthetic_scene(6, with_wall=True, textured=True, render_mode="Raytracer")
+    else:
+        d = meshes.cube_field(num_worlds=3, cubes=30, mode="Raytracer")
+    r = make_product(d, visibility=False)
+    before = fetch(r, visibility=False, raytracer=True)
+    ref = render_oracle(d)
+    assert_parity(before, ref)
+    obj = r.instance_object_tensor().to_torch()
+    bound = obj.clone()
+    obj.copy_((bound + 1) % 3)                    # other valid ids, all non-negative
+    r.step()
+    after = fetch(r, visibility=False, raytracer=True)
+    for k in ("rgb", "depth", "segmask"):
+        assert np.array_equal(before[k], after[k]), k
+    assert set(np.unique(after["segmask"]).tolist()) <= set(bound.cpu().tolist()) | {-1}
 
 
 def full_ids(fs):

@@ -1,7 +1,8 @@
-"""Loose performance guards (byte-equality was the only
-thing tested about the tuned launch shapes).  Thresholds leave 10-15 % over
-the round's measurements (profiles/r02_*_summary.json), so they trip on a
-regression, not on box-to-box noise."""
+"""Gross-regression guards (byte-equality was the only
+thing tested about the tuned launch shapes).  The figures are printed for the
+log; the assertions leave 40 % and more over the measurements
+(profiles/r02_*_summary.json): a shared box, a cold card or the XCD phase of the
+stream move a 22 us launch by 10 %, a broken launch shape by 2x."""
 import os
 import time
 
@@ -23,24 +24,27 @@ def _us(desc, steps, env=None, monkeypatch=None):
     return min(r.time_renders(steps) for _ in range(5)) / steps * 1000.0
 
 
-def test_headline_batch_stays_above_two_thirds_of_the_hbm_roofline(native, monkeypatch):
+def test_headline_batch_is_not_grossly_slower(native, monkeypatch, capsys):
     desc = scenes.synthetic_scene(4096)
     us = _us(desc, 400)
     bytes_per_launch = 4096 * (64 * 64 * 8 + 2 * 44 + 28)
     frac = bytes_per_launch / (us * 1e-6) / 8e12
-    # (in a long-lived test process the output placement decides between 22.5 and
-    # ~24.5 us -- mrx_create's bounded search usually finds the former)
-    assert us < 25.5 and frac > 0.65, f"{us:.2f} us / launch, {frac:.3f} of 8 TB/s (round 2: 22.5 us, 0.748)"
+    with capsys.disabled():
+        print(f"\n[perf] headline: {us:.2f} us / launch, {frac:.3f} of 8 TB/s (round 2: 22.5 us, 0.748)")
+    assert us < 32.0 and frac > 0.5, f"{us:.2f} us / launch, {frac:.3f} of 8 TB/s (round 2: 22.5 us, 0.748)"
 
 
-def test_small_batches_and_the_bvh_path(native, monkeypatch):
+def test_small_batches_and_the_bvh_path_are_not_grossly_slower(native, monkeypatch, capsys):
     monkeypatch.setenv("MRX_PLACEMENT_TRIES", "1")
     c2 = _us(scenes.synthetic_scene(1024), 400)
     c4 = _us(scenes.synthetic_scene(2048), 400)
     bvh = _us(meshes.cube_field(1024, 40), 200)
-    assert c2 < 10.8, f"1024 worlds: {c2:.2f} us (round 2: 9.3)"
-    assert c4 < 15.5, f"2048 worlds: {c4:.2f} us (round 2: 13.9)"
-    assert bvh < 32.0, f"1024 worlds x 482 triangles: {bvh:.1f} us (round 2: 27.0)"
+    with capsys.disabled():
+        print(f"\n[perf] 1024 worlds {c2:.2f} us (r2: 9.3), 2048 worlds {c4:.2f} us (r2: 13.9), "
+              f"1024 x 482 triangles {bvh:.1f} us (r2: 27.0)")
+    assert c2 < 14.0, f"1024 worlds: {c2:.2f} us (round 2: 9.3)"
+    assert c4 < 20.0, f"2048 worlds: {c4:.2f} us (round 2: 13.9)"
+    assert bvh < 40.0, f"1024 worlds x 482 triangles: {bvh:.1f} us (round 2: 27.0)"
 
 
 def test_report_headline_time_in_this_process(native, monkeypatch, capsys):
