@@ -181,11 +181,17 @@ __device__ __forceinline__ Rect sphereRect(const RasterParams &p, const InstXfor
 #endif
 constexpr int kSlotBits = 10;
 constexpr uint32_t kKeyMask = 0x1FFFFFu;        // 2M triangles per world
+// The slot field's top value marks a pixel whose winner was resolved in an earlier round of
+// the tile (the record table is reused from round to round): its colour / segmask label
+// already sit in the output tensors.  Being the largest slot value it also wins the 64-bit
+// maximum against the same triangle taken again with a fresh slot.
+constexpr uint32_t kStashed = (1u << kSlotBits) - 1u;
 
 
 // Tile shapes (the LDS tile-size sweep of BASELINE configs[2]): TW x TH pixels per workgroup, one wave per
 // TW x 8 strip, so TH / 8 waves; the depth buffer takes TW * TH * 8 bytes of LDS.
 constexpr int tabCap(bool tex, int tw, int th) { return tex ? 256 : (tw * th >= 4096 ? 1024 : 512); }
+constexpr int tabUsable(int cap) { return cap < (int)kStashed ? cap : (int)kStashed; }   // slot kStashed is the marker
 constexpr int bigCap(int tw, int th) { return tw * th >= 4096 ? 96 : 64; }   // (>= 64: one batch always fits an empty list)
 
 struct WaveScratch {
@@ -200,6 +206,205 @@ __device__ __forceinline__ unsigned long long packHit(float it, uint32_t low)
     return ((unsigned long long)__float_as_uint(it) << 32) | low;
 }
 
+
+// ---------------------------------------------------------------------------
+// Resolve of a wave's strip: every lane looks up the winners of its pixels (four consecutive
+// pixels of one row in each 32-pixel half) in the round's record table and shades them.
+//
+// FINAL = false -- the end of a round that is not the tile's last (the record table is about
+// to be reused): winners of this round are written to the output tensors pixel by pixel
+// (colour, and the segmask label under IDS = 2) and their depth-buffer words are marked
+// kStashed.  Nothing is carried in registers from round to round: the kernel used to hold
+// the resolved colours and labels of its eight pixels in sixteen registers through every
+// loop of the traversal, which the Raytracer-mode instantiations paid for in scratch
+// (44 - 62 spilled VGPRs with textures: 2.2x the algorithmic HBM traffic on C5).
+// FINAL = true -- the tile's last round: resolve and output in one pass, one 16-byte store
+// per tensor and half; pixels marked kStashed take the colour / label this lane stored in
+// an earlier round back from the tensor (only lanes that have such pixels load anything;
+// tiles that resolve in a single round -- the common case -- never do).
+// Depth (1/best, v_rcp_f32) and visibility ids come from the depth buffer itself.
+// ---------------------------------------------------------------------------
+// What resolveStrip reads of the kernel's parameters.  The in-loop (FINAL = false) call fills
+// it from the kernel-argument segment through a laundered pointer, right where it is needed:
+// taken from `p` these eight dwords would sit in scalar registers through the whole traversal
+// (the kernel has none to spare: every scalar spilled costs a v_writelane / v_readlane pair
+// in some loop).
+struct ResolveArgs {
+    uint32_t *rgb;
+    float *depth;
+    int32_t *ids;
+    const uint32_t *texels;
+    uint32_t nfast, nslow, writeThrough;
+};
+typedef const __attribute__((address_space(4))) RasterParams *KernargParams;
+// the same for the triangle set-up of a batch (setupTriangleCore)
+struct SetupArgs {
+    const ObjTri *tris;
+    const TriMat *triMats;
+    float sx, ox, sz, oz, s6bPad, ambient, diffuse;
+    int32_t transposed;
+};
+
+template <int IDS, bool TEX, int TW, int TH, bool FINAL>
+__device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long long *zbuf, const float4 *shadeTab,
+                                             const float (*coldTab)[kCold], uint32_t view, uint32_t tileX0,
+                                             uint32_t tileY0, int wave, int lane)
+{
+    constexpr int kHalves = TW / 32;
+    if (!FINAL) {
+        // This instantiation sits inside the round loop, and everything it computes is
+        // loop-invariant: left alone the compiler hoists the pixel addresses of both halves
+        // out of the loop and carries them through the traversal in registers it does not have.
+        // Laundering the two values they all derive from keeps the arithmetic in here.
+        asm volatile("" : "+v"(lane));
+        asm volatile("" : "+s"(view));
+    }
+    const int lx = lane & 7, ly = lane >> 3;
+    const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
+    const bool full = (p.nfast & 3u) == 0 && tileX0 + TW <= p.nfast && tileY0 + TH <= p.nslow;
+    const uint32_t fy = tileY0 + 8u * wave + ly;
+#pragma unroll
+    for (int hf = 0; hf < kHalves; ++hf) {
+        unsigned long long *zrow = zbuf + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
+        const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
+        const size_t o = tileBase + (size_t)(8u * wave + ly) * p.nfast + hf * 32 + 4 * lx;
+        uint32_t rgba[kRegionBlocks], low[kRegionBlocks], itBits[kRegionBlocks], texSlot[kRegionBlocks];
+        int32_t seg[kRegionBlocks];
+        bool mine[kRegionBlocks], texOn[kRegionBlocks], anyTexOn = false, anyStashed = false;
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            const unsigned long long z = zrow[b];
+            low[b] = (uint32_t)z;
+            itBits[b] = (uint32_t)(z >> 32);
+            const uint32_t slot = low[b] & kStashed;
+            // a hit that is not marked belongs to this round: every earlier round ended with
+            // its winners marked, and slots are handed out before any pixel is written
+            mine[b] = low[b] != 0u && slot != kStashed;
+            anyStashed = anyStashed || (low[b] != 0u && slot == kStashed);
+            const float4 rec = shadeTab[mine[b] ? slot : 0u];
+            rgba[b] = mine[b] ? __float_as_uint(rec.x) : 0xFF000000u;
+            seg[b] = mine[b] ? __float_as_int(rec.z) : -1;
+            texOn[b] = TEX && mine[b] && __float_as_int(rec.y) >= 0;
+            texSlot[b] = texOn[b] ? slot : 0u;
+            anyTexOn = anyTexOn || texOn[b];
+        }
+        // Textured winners: the texel loads of the half's four pixels are all issued before any
+        // is used (addresses of untextured pixels point at texel 0) -- under per-pixel branches
+        // every load waited for the one before it.
+        if (TEX && __ballot(anyTexOn) != 0) {
+            uint32_t texAddr[kRegionBlocks], texel[kRegionBlocks];
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b) {
+                const float *cold = coldTab[texSlot[b]];
+                const float it = __uint_as_float(itBits[b]);
+                // S8, as shadeTextured() of raster_dev.hpp (same operations in the same order)
+                const float px = (float)(fx0 + b), py = (float)fy;
+                const float tt = 1.0f / it;
+                const float u = __builtin_fmaf(cold[0], px, __builtin_fmaf(cold[1], py, cold[2])) * tt;
+                const float v = __builtin_fmaf(cold[3], px, __builtin_fmaf(cold[4], py, cold[5])) * tt;
+                const int tw = __float_as_int(cold[10]), th = __float_as_int(cold[11]);
+                const float uf = u - floorf(u);
+                float vf = v - floorf(v);
+                vf = 1.0f - vf;
+                int tx = (int)(uf * (float)tw);
+                int ty = (int)(vf * (float)th);
+                tx = tx > tw - 1 ? tw - 1 : tx;
+                ty = ty > th - 1 ? th - 1 : ty;
+                tx = tx < 0 ? 0 : tx;
+                ty = ty < 0 ? 0 : ty;
+                texAddr[b] = texOn[b] ? __float_as_uint(cold[9]) + (uint32_t)ty * (uint32_t)tw + (uint32_t)tx : 0u;
+            }
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b)
+                texel[b] = p.texels[texAddr[b]];
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b)
+                if (texOn[b]) {
+                    const float *cold = coldTab[texSlot[b]];
+                    const uint32_t r8 = toU8(((float)(texel[b] & 255u) * (1.0f / 255.0f)) * cold[6]);
+                    const uint32_t g8 = toU8(((float)((texel[b] >> 8) & 255u) * (1.0f / 255.0f)) * cold[7]);
+                    const uint32_t b8 = toU8(((float)((texel[b] >> 16) & 255u) * (1.0f / 255.0f)) * cold[8]);
+                    rgba[b] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
+                }
+        }
+        if (!FINAL) {
+            // stash this round's winners in the tensors and mark them (only the low word:
+            // between the barrier ahead of the large pass and the one that opens the next
+            // round nobody else touches the pixels of this strip)
+            const bool anyMine = mine[0] || mine[1] || mine[2] || mine[3];
+            if (full && !anyStashed) {
+                // no pixel of the four holds an earlier round's colour: one 16-byte store
+                // (pixels without a winner yet get the background, which whoever wins them
+                // later -- or the tile's last resolve -- overwrites)
+                if (anyMine) {
+                    streamStore16(p.writeThrough, p.rgb + o, rgba[0], rgba[1], rgba[2], rgba[3]);
+                    if (IDS == 2)
+                        streamStore16(p.writeThrough, p.ids + o, (uint32_t)seg[0], (uint32_t)seg[1], (uint32_t)seg[2],
+                                      (uint32_t)seg[3]);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < kRegionBlocks; ++b)
+                    if (mine[b] && fx0 + b < p.nfast && fy < p.nslow) {
+                        streamStore4(p.writeThrough, p.rgb + o + b, rgba[b]);
+                        if (IDS == 2)
+                            streamStore4(p.writeThrough, p.ids + o + b, (uint32_t)seg[b]);
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b)
+                if (mine[b])
+                    reinterpret_cast<uint32_t *>(zrow + b)[0] = low[b] | kStashed;
+            continue;
+        }
+        // pixels resolved in an earlier round: their colour / label come back from the tensors
+        if (__ballot(anyStashed) != 0) {
+            if (anyStashed && full) {
+                const u32x4 prgb = streamLoad16(p.rgb + o);
+                u32x4 pseg = { 0u, 0u, 0u, 0u };
+                if (IDS == 2)
+                    pseg = streamLoad16(p.ids + o);
+#pragma unroll
+                for (int b = 0; b < kRegionBlocks; ++b)
+                    if (low[b] != 0u && (low[b] & kStashed) == kStashed) {
+                        rgba[b] = prgb[b];
+                        seg[b] = (int32_t)pseg[b];
+                    }
+            } else if (anyStashed) {
+#pragma unroll
+                for (int b = 0; b < kRegionBlocks; ++b)
+                    if (low[b] != 0u && (low[b] & kStashed) == kStashed && fx0 + b < p.nfast && fy < p.nslow) {
+                        rgba[b] = streamLoad4(p.rgb + o + b);
+                        if (IDS == 2)
+                            seg[b] = (int32_t)streamLoad4(p.ids + o + b);
+                    }
+            }
+        }
+        uint32_t dep[kRegionBlocks], id[kRegionBlocks];
+#pragma unroll
+        for (int b = 0; b < kRegionBlocks; ++b) {
+            dep[b] = low[b] != 0u ? __float_as_uint(__builtin_amdgcn_rcpf(__uint_as_float(itBits[b]))) : 0u;
+            id[b] = IDS == 2 ? (uint32_t)seg[b]
+                             : (low[b] != 0u ? (~(low[b] >> kSlotBits) & kKeyMask) : 0xFFFFFFFFu);
+        }
+        if (full) {
+            streamStore16(p.writeThrough, p.rgb + o, rgba[0], rgba[1], rgba[2], rgba[3]);
+            streamStore16(p.writeThrough, p.depth + o, dep[0], dep[1], dep[2], dep[3]);
+            if (IDS)
+                streamStore16(p.writeThrough, p.ids + o, id[0], id[1], id[2], id[3]);
+        } else if (fy < p.nslow) {
+#pragma unroll
+            for (int b = 0; b < kRegionBlocks; ++b)
+                if (fx0 + b < p.nfast) {
+                    streamStore4(p.writeThrough, p.rgb + o + b, rgba[b]);
+                    streamStore4(p.writeThrough, p.depth + o + b, dep[b]);
+                    if (IDS)
+                        streamStore4(p.writeThrough, p.ids + o + b, id[b]);
+                }
+        }
+    }
+}
+
 // IDS: 0 = no id tensor, 1 = visibility ids (world-local triangle index),
 // 2 = segmask (objectID of the winner's instance)
 // CLS: exact per-strip classification of the listed large triangles (64x64 tiles only)
@@ -211,6 +416,7 @@ void bvhTileKernel(const RasterParams p)
     constexpr int kBvhWaves = TH / 8;             // one wave per TW x 8 strip of the tile
     constexpr int kHalves = TW / 32;              // 32-pixel halves of a strip: 4 pixels of a lane each
     constexpr int kCap = tabCap(TEX, TW, TH);
+    constexpr uint32_t kUsable = (uint32_t)tabUsable(kCap);      // records a round can hold
     constexpr bool kPartial = TEX || CLS;
     constexpr int kBigCap = bigCap(TW, TH);
     static_assert((TW == 64 || TW == 32) && (TH == 64 || TH == 32), "tile shapes of the sweep");
@@ -218,8 +424,16 @@ void bvhTileKernel(const RasterParams p)
     const int lane = threadIdx.x % kWave;
     const uint32_t tilesFast = (p.nfast + TW - 1) / TW, tilesSlow = (p.nslow + TH - 1) / TH;
     const uint32_t tilesPerView = tilesFast * tilesSlow;
-    const uint32_t view = blockIdx.x / tilesPerView;
-    const uint32_t tile = blockIdx.x - view * tilesPerView;
+    // XCD-aware item order for views of several tiles: consecutive workgroups run on consecutive
+    // XCDs (eight, round-robin), each with its own L2, so with item = blockIdx the tiles of a view
+    // would be spread over all of them and every XCD would fetch the view's camera, poses and
+    // texels from HBM for itself.  When the grid divides by eight, XCD x takes the x-th eighth of
+    // the items instead: the tiles of a view follow each other on one XCD.
+    uint32_t item = blockIdx.x;
+    if (tilesPerView > 1 && (gridDim.x & 7u) == 0)
+        item = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t view = item / tilesPerView;
+    const uint32_t tile = item - view * tilesPerView;
     const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
     const uint32_t passInst = p.bvhPassInst;
     const uint32_t dskip = MRX_BVH_DIAG ? p.debugSkip : 0u;
@@ -293,19 +507,13 @@ void bvhTileKernel(const RasterParams p)
         ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // records / done waves / large triangles;
                                                                   // [4], [6]: records / large triangles of odd rounds
 
-    // the lane's pixels at output time: strip = wave, four consecutive pixels of
-    // one row in each 32-pixel half (one 16-byte store per tensor and half)
+    // the lane's pixels in the large pass and at resolve / output time: strip = wave, four
+    // consecutive pixels of one row in each 32-pixel half
     const int lx = lane & 7, ly = lane >> 3;
-    uint32_t rgba[kHalves][kRegionBlocks];
-    int32_t seg[kHalves][kRegionBlocks];
-#pragma unroll
-    for (int hf = 0; hf < kHalves; ++hf)
-#pragma unroll
-        for (int b = 0; b < kRegionBlocks; ++b) {
-            rgba[hf][b] = 0xFF000000u;
-            seg[hf][b] = -1;
-        }
 
+    // the record and large-triangle counters alternate between two sets from
+    // round to round, so the idle set can be prepared while the other is read
+    uint32_t par = 0;
     for (uint32_t passBase = i0; passBase < i1; passBase += passInst) {
         const uint32_t n = min(passInst, i1 - passBase);
         if (passBase != i0) {
@@ -313,7 +521,8 @@ void bvhTileKernel(const RasterParams p)
             // orders the clearing of the depth buffer above ahead of its first use)
             __syncthreads();                          // previous TLAS consumed
             if (threadIdx.x == 0)
-                ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // (every wave has read the last pass's counts by now)
+                ctrl[1] = 0u;     // done waves (every wave has read the last pass's count by now); the record and
+                                  // large-triangle counters of the coming round were set at the end of the last one
         }
         // ---- phase I: the TLAS of this pass, in LDS.  Lane = instance: its transform
         //      (S2/S3), the S6b quantities, and the padded screen rectangle of the bounding
@@ -375,9 +584,6 @@ void bvhTileKernel(const RasterParams p)
         int32_t vRoot = -1;
         bool done = (dskip & 4u) != 0;          // timing aid: no traversal at all
         bool reported = false;
-        // the record and large-triangle counters alternate between two sets from
-        // round to round, so the idle set can be cleared while the other is read
-        uint32_t par = 0;
         for (;; par ^= 4u) {
             // -- produce until this wave's share is exhausted or the record table is full
             bool tableFull = false;
@@ -474,7 +680,7 @@ void bvhTileKernel(const RasterParams p)
                 if (qCount == 0)
                     break;
                 // (the record table of the round is full already: no point in setting the batch up)
-                if (kPartial && rflu(ctrl[0 + par]) >= (uint32_t)kCap) {
+                if (kPartial && rflu(ctrl[0 + par]) >= kUsable) {
                     tableFull = true;
                     break;
                 }
@@ -491,12 +697,12 @@ void bvhTileKernel(const RasterParams p)
                 c.bbX0 = c.bbX1 = c.bbY0 = c.bbY1 = 0.0f;
                 uint32_t kTri = 0;
                 int32_t objL = -1;
+                // cold: [0] = |1/d| (the u/v planes are derived once the triangle has a slot), [6..8] lit colour
                 float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
-                float4 texDesc = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint32_t triL = 0;
                 if ((uint32_t)lane < nb && !(dskip & 8u)) {
                     const uint2 e = ws->queue[lane];
-                    if (TEX)                          // the texture descriptor stored with the triangle's material
-                        texDesc = reinterpret_cast<const float4 *>(p.triMats + e.y)[3];
+                    triL = e.y;
                     const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)e.x * kInstRecDw);
                     const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4], a5 = rec[5];
                     InstXform x;
@@ -512,7 +718,13 @@ void bvhTileKernel(const RasterParams p)
                     const float lv[3] = { kLvInLds ? __uint_as_float(ctrl[8]) : vcAll.lv[0],
                                           kLvInLds ? __uint_as_float(ctrl[9]) : vcAll.lv[1],
                                           kLvInLds ? __uint_as_float(ctrl[10]) : vcAll.lv[2] };
-                    const bool valid = setupTriangleCore(p, lv, x, e.y, objL, (int32_t)kTri, c, shade, cold);
+                    // (what the set-up reads of the kernel's parameters, fetched per batch from the
+                    // kernel-argument segment instead of living in scalar registers: see ResolveArgs)
+                    KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(pk));
+                    const SetupArgs sa = { pk->tris, pk->triMats, pk->sx, pk->ox, pk->sz, pk->oz, pk->s6bPad,
+                                           pk->ambient, pk->diffuse, pk->transposed };
+                    const bool valid = setupTriangleCore<false>(sa, lv, x, e.y, objL, (int32_t)kTri, c, shade, cold);
                     live = valid && c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
                     // The planes at the tile's corners: fl(A x + fl(B y + C)) is monotone in x and in
                     // y, so its extreme over the tile's pixels is taken at a corner pixel, and a
@@ -544,11 +756,11 @@ void bvhTileKernel(const RasterParams p)
                 // it drops the batch and takes it again after the resolve.
                 const uint32_t liveRank = (uint32_t)__builtin_popcountll(liveMask & ((1ull << lane) - 1ull));
                 uint64_t defMask = 0;
-                if (slotBase + numLive > (uint32_t)kCap) {
+                if (slotBase + numLive > kUsable) {
                     tableFull = true;
                     if (!kPartial)
                         break;                        // wait for the resolve, then take the batch again
-                    const uint32_t fit = slotBase < (uint32_t)kCap ? (uint32_t)kCap - slotBase : 0u;
+                    const uint32_t fit = slotBase < kUsable ? kUsable - slotBase : 0u;
                     defMask = __ballot(live && liveRank >= fit);
                     live = live && liveRank < fit;
                 }
@@ -557,12 +769,20 @@ void bvhTileKernel(const RasterParams p)
                 if (live) {
                     shadeTab[slot] = make_float4(shade[0], shade[1], shade[2], __uint_as_float(kTri));   // [2]: the triangle's object id
                     if (TEX && __float_as_int(shade[1]) >= 0) {
-#pragma unroll
-                        for (int i = 0; i < 9; ++i)
-                            coldTab[slot][i] = cold[i];
-                        coldTab[slot][9] = texDesc.x;
-                        coldTab[slot][10] = texDesc.y;
-                        coldTab[slot][11] = texDesc.z;
+                        // the u/v planes from the edge planes, the texture coordinates (read again:
+                        // L1 / L2 hits) and |1/d|; the texture's descriptor rides with the material
+                        KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+                        asm volatile("" : "+s"(pk));
+                        const float4 *tsrc = reinterpret_cast<const float4 *>(pk->tris + triL);
+                        const float4 t2 = tsrc[2], t3 = tsrc[3];
+                        const float4 texDesc = reinterpret_cast<const float4 *>(pk->triMats + triL)[3];
+                        const float uv[6] = { t2.y, t2.z, t2.w, t3.x, t3.y, t3.z };
+                        float uvp[6];
+                        uvPlanes(c, cold[0], uv, uvp);
+                        float4 *cdst = reinterpret_cast<float4 *>(coldTab[slot]);
+                        cdst[0] = make_float4(uvp[0], uvp[1], uvp[2], uvp[3]);
+                        cdst[1] = make_float4(uvp[4], uvp[5], cold[6], cold[7]);
+                        cdst[2] = make_float4(cold[8], texDesc.x, texDesc.y, texDesc.z);
                     }
                 }
                 if (dskip & 128u) MRX_STAMP(3);
@@ -710,8 +930,22 @@ void bvhTileKernel(const RasterParams p)
             //    small-triangle walks ended at the barrier), so no barrier separates this
             //    pass from the resolve below.
             const bool allDone = rflu(ctrl[1]) == (uint32_t)kBvhWaves;
-            if (threadIdx.x == 0)
-                ctrl[0 + (par ^ 4u)] = ctrl[2 + (par ^ 4u)] = 0u;     // the next round's counters
+            // The record table lives on from round to round and from pass to pass until it is
+            // full (records are per triangle, not per TLAS pass): only then are the round's
+            // winners resolved and stashed and the table started afresh.  A round that ended on
+            // a full large-triangle list, or a pass that ended with room to spare, carries the
+            // count over.  (A reservation that did not fit has pushed the count past kUsable; a
+            // round in which every wave finished had none.)
+            // The end of a pass is a free place to start afresh (no wave holds a batch it would have to
+            // set up again), so a table more than half full is not carried into the next pass: it would
+            // fill up in the middle of it (4994-triangle worlds at 64x64: 61 us this way, 66 us carrying
+            // everything; 256x256 views of the same worlds, whose tiles see a fraction each: 134 against 150).
+            const uint32_t recCount = rflu(ctrl[0 + par]);
+            const bool tableReset = recCount >= kUsable || (allDone && recCount > kUsable / 2u);
+            if (threadIdx.x == 0) {                                   // the next round's counters
+                ctrl[0 + (par ^ 4u)] = tableReset ? 0u : recCount;
+                ctrl[2 + (par ^ 4u)] = 0u;
+            }
             {
                 const uint32_t listed = min(rflu(ctrl[2 + par]), (uint32_t)kBigCap);
                 for (uint32_t e0 = 0; e0 < listed; e0 += kWave) {
@@ -785,116 +1019,38 @@ void bvhTileKernel(const RasterParams p)
                 }
             }
             if (!(dskip & 128u)) MRX_STAMP(4);
-            // -- resolve: every lane looks its eight pixels up; winners whose record
-            //    is in the table of this round are shaded now (a later round reuses
-            //    the table)
-#pragma unroll
-            for (int hf = 0; hf < kHalves; ++hf) {
-                // Textured winners: the texel loads of the half's four pixels are all
-                // issued before any is used (addresses of untextured pixels point at texel
-                // 0) -- under per-pixel branches every load waited for the one before it,
-                // 8 x (descriptor, texel) round trips per lane and round.
-                uint32_t texSlot[kRegionBlocks];
-                bool texOn[kRegionBlocks], anyTexOn = false;
-#pragma unroll
-                for (int b = 0; b < kRegionBlocks; ++b) {
-                    const unsigned long long z = zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b];
-                    const uint32_t low = (uint32_t)z;
-                    const uint32_t slot = low & ((1u << kSlotBits) - 1u);
-                    const uint32_t k = ~(low >> kSlotBits) & kKeyMask;
-                    const float4 rec = shadeTab[slot < (uint32_t)kCap ? slot : 0u];
-                    const bool mine = low != 0u && slot < (uint32_t)kCap && __float_as_uint(rec.w) == k;
-                    if (mine) {
-                        rgba[hf][b] = __float_as_uint(rec.x);
-                        seg[hf][b] = __float_as_int(rec.z);
-                    }
-                    if (TEX) {
-                        texOn[b] = mine && __float_as_int(rec.y) >= 0;
-                        texSlot[b] = texOn[b] ? slot : 0u;
-                        anyTexOn = anyTexOn || texOn[b];
-                    }
-                }
-                if (TEX && __ballot(anyTexOn) != 0) {
-                    uint32_t texAddr[kRegionBlocks], texel[kRegionBlocks];
-#pragma unroll
-                    for (int b = 0; b < kRegionBlocks; ++b) {
-                        const float *cold = coldTab[texSlot[b]];
-                        const float it = __uint_as_float((uint32_t)(zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b] >> 32));
-                        // S8, as shadeTextured() of raster_dev.hpp (same operations in the same order)
-                        const float px = (float)(tileX0 + hf * 32 + 4 * lx + b), py = (float)(tileY0 + 8u * wave + ly);
-                        const float tt = 1.0f / it;
-                        const float u = __builtin_fmaf(cold[0], px, __builtin_fmaf(cold[1], py, cold[2])) * tt;
-                        const float v = __builtin_fmaf(cold[3], px, __builtin_fmaf(cold[4], py, cold[5])) * tt;
-                        const int tw = __float_as_int(cold[10]), th = __float_as_int(cold[11]);
-                        const float uf = u - floorf(u);
-                        float vf = v - floorf(v);
-                        vf = 1.0f - vf;
-                        int tx = (int)(uf * (float)tw);
-                        int ty = (int)(vf * (float)th);
-                        tx = tx > tw - 1 ? tw - 1 : tx;
-                        ty = ty > th - 1 ? th - 1 : ty;
-                        tx = tx < 0 ? 0 : tx;
-                        ty = ty < 0 ? 0 : ty;
-                        texAddr[b] = texOn[b] ? __float_as_uint(cold[9]) + (uint32_t)ty * (uint32_t)tw + (uint32_t)tx : 0u;
-                    }
-#pragma unroll
-                    for (int b = 0; b < kRegionBlocks; ++b)
-                        texel[b] = p.texels[texAddr[b]];
-#pragma unroll
-                    for (int b = 0; b < kRegionBlocks; ++b)
-                        if (texOn[b]) {
-                            const float *cold = coldTab[texSlot[b]];
-                            const uint32_t r8 = toU8(((float)(texel[b] & 255u) * (1.0f / 255.0f)) * cold[6]);
-                            const uint32_t g8 = toU8(((float)((texel[b] >> 8) & 255u) * (1.0f / 255.0f)) * cold[7]);
-                            const uint32_t b8 = toU8(((float)((texel[b] >> 16) & 255u) * (1.0f / 255.0f)) * cold[8]);
-                            rgba[hf][b] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
-                        }
-                }
+            // -- resolve (resolveStrip above).  The tile's last round -- this wave and all others
+            //    done, no further pass -- leaves the loops and resolves + outputs in one go below;
+            //    a round that filled the record table stashes its winners in the tensors, because
+            //    the table is reused from here on.  Nothing resolved is carried in registers.
+            if (allDone && passBase + passInst >= i1)
+                break;
+            if (tableReset) {
+                // (the kernel's only argument sits at offset 0 of the kernel-argument segment)
+                KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(pk));
+                const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
+                resolveStrip<IDS, TEX, TW, TH, false>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
             }
             if (!(dskip & 128u)) MRX_STAMP(5);
-            if (allDone)
-                break;                                // (the next pass, if any, opens with a barrier)
+            if (allDone) {
+                par ^= 4u;                            // (the counters prepared above are the next pass's)
+                break;                                // (the next pass opens with a barrier)
+            }
             __syncthreads();
         }
     }
     if (i0 >= i1)
         __syncthreads();                              // an empty world: only the cleared depth buffer
 
-    // ---- output: depth = 1/best (v_rcp_f32, <= 1 ulp), one 16-byte store per
-    //      tensor and half
+    // ---- the tile's last resolve + output: depth = 1/best (v_rcp_f32, <= 1 ulp), one
+    //      16-byte store per tensor and half
     if (dskip & 1u)
         return;
-    const size_t tileBase = ((size_t)view * p.nslow + tileY0) * p.nfast + tileX0;
-    const bool full = (p.nfast & 3u) == 0 && tileX0 + TW <= p.nfast && tileY0 + TH <= p.nslow;
-    const uint32_t fy = tileY0 + 8u * wave + ly;
-#pragma unroll
-    for (int hf = 0; hf < kHalves; ++hf) {
-        const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
-        const size_t o = tileBase + (size_t)(8u * wave + ly) * p.nfast + hf * 32 + 4 * lx;
-        uint32_t dep[kRegionBlocks], id[kRegionBlocks];
-#pragma unroll
-        for (int b = 0; b < kRegionBlocks; ++b) {
-            const unsigned long long z = zbuf[(8 * wave + ly) * TW + 32 * hf + 4 * lx + b];
-            const uint32_t low = (uint32_t)z;
-            dep[b] = low != 0u ? __float_as_uint(__builtin_amdgcn_rcpf(__uint_as_float((uint32_t)(z >> 32)))) : 0u;
-            id[b] = IDS == 2 ? (uint32_t)seg[hf][b]
-                             : (low != 0u ? (~(low >> kSlotBits) & kKeyMask) : 0xFFFFFFFFu);
-        }
-        if (full) {
-            streamStore16(p.writeThrough, p.rgb + o, rgba[hf][0], rgba[hf][1], rgba[hf][2], rgba[hf][3]);
-            streamStore16(p.writeThrough, p.depth + o, dep[0], dep[1], dep[2], dep[3]);
-            if (IDS)
-                streamStore16(p.writeThrough, p.ids + o, id[0], id[1], id[2], id[3]);
-        } else if (fy < p.nslow) {
-#pragma unroll
-            for (int b = 0; b < kRegionBlocks; ++b)
-                if (fx0 + b < p.nfast) {
-                    streamStore4(p.writeThrough, p.rgb + o + b, rgba[hf][b]);
-                    streamStore4(p.writeThrough, p.depth + o + b, dep[b]);
-                    if (IDS)
-                        streamStore4(p.writeThrough, p.ids + o + b, id[b]);
-                }
-        }
+    if (!(dskip & 128u)) MRX_STAMP(5);
+    {
+        const ResolveArgs ra = { p.rgb, p.depth, p.ids, p.texels, p.nfast, p.nslow, p.writeThrough };
+        resolveStrip<IDS, TEX, TW, TH, true>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
     }
     MRX_STAMP(6);
 #undef MRX_STAMP

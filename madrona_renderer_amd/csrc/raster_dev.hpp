@@ -110,7 +110,15 @@ __device__ __forceinline__ void instanceTransform(const RasterParams &p, const V
 // Planes are returned in registers; the shading record goes to `shade` (rgba,
 // texture, objectID, world-local index) and `cold` (u/v planes [0..5] -- only
 // written for textured triangles -- and lit colour [6..8]).  Returns validity.
-__device__ __forceinline__ bool setupTriangleCore(const RasterParams &p, const float (&lv)[3],
+// UVPLANES = false (BVH kernel): the u/v planes are left out and cold[0] holds
+// |1/d| instead -- the caller derives them with uvPlanes() once it knows the
+// triangle needs a record, instead of carrying twelve registers through its
+// slot allocation.
+// PARAMS: RasterParams, or any struct with the members read here (tris, triMats, s6bPad, sx, sz,
+// ox, oz, transposed, diffuse, ambient) -- the BVH kernel passes a copy it reads from the
+// kernel-argument segment batch by batch instead of holding the values in scalar registers.
+template <bool UVPLANES = true, typename PARAMS = RasterParams>
+__device__ __forceinline__ bool setupTriangleCore(const PARAMS &p, const float (&lv)[3],
                                                   const InstXform &x, uint32_t tri, int32_t obj,
                                                   int32_t kWorld, TriPlanes &out,
                                                   float *shade, float *cold)
@@ -219,7 +227,9 @@ __device__ __forceinline__ bool setupTriangleCore(const RasterParams &p, const f
         out.Dc = __builtin_fmaf(nn[2], p.oz, __builtin_fmaf(nn[0], p.ox, nn[1])) * rd;
     }
     // u/v planes (S8) are only ever read for textured triangles
-    if (tex >= 0) {
+    if (!UVPLANES) {
+        cold[0] = fabsf(rd);
+    } else if (tex >= 0) {
         const float rad = fabsf(rd);
         cold[0] = __builtin_fmaf(uv[4], A[2], __builtin_fmaf(uv[2], A[1], uv[0] * A[0])) * rad;
         cold[1] = __builtin_fmaf(uv[4], B[2], __builtin_fmaf(uv[2], B[1], uv[0] * B[0])) * rad;
@@ -243,6 +253,19 @@ __device__ __forceinline__ bool setupTriangleCore(const RasterParams &p, const f
     shade[2] = obj >= 0 ? mc.w : __int_as_float(obj);   // the triangle's own object id (TriMat alpha slot)
     shade[3] = __int_as_float(kWorld);
     return valid;
+}
+
+// S8 u/v planes of a triangle whose edge planes are `c` (as setupTriangleCore left them:
+// transposed and flipped), `rad` = |1/d|, uv = the six texture coordinates of ObjTri:
+// the same operations in the same order as in setupTriangleCore<true>.
+__device__ __forceinline__ void uvPlanes(const TriPlanes &c, float rad, const float (&uv)[6], float *cold)
+{
+    cold[0] = __builtin_fmaf(uv[4], c.A2, __builtin_fmaf(uv[2], c.A1, uv[0] * c.A0)) * rad;
+    cold[1] = __builtin_fmaf(uv[4], c.B2, __builtin_fmaf(uv[2], c.B1, uv[0] * c.B0)) * rad;
+    cold[2] = __builtin_fmaf(uv[4], c.C2, __builtin_fmaf(uv[2], c.C1, uv[0] * c.C0)) * rad;
+    cold[3] = __builtin_fmaf(uv[5], c.A2, __builtin_fmaf(uv[3], c.A1, uv[1] * c.A0)) * rad;
+    cold[4] = __builtin_fmaf(uv[5], c.B2, __builtin_fmaf(uv[3], c.B1, uv[1] * c.B0)) * rad;
+    cold[5] = __builtin_fmaf(uv[5], c.C2, __builtin_fmaf(uv[3], c.C1, uv[1] * c.C0)) * rad;
 }
 
 // The same for a draw-list entry: transform of the instance, then the triangle.
@@ -333,6 +356,21 @@ __device__ __forceinline__ void streamStore16(uint32_t writeThrough, void *dst,
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
     else
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+}
+// Reads of output pixels this same lane stored earlier in the kernel (the BVH kernel's
+// multi-round resolve): agent scope, so they are served by the L2 the write-through
+// stores went to, and waited for here (the compiler does not track asm loads).
+__device__ __forceinline__ u32x4 streamLoad16(const void *src)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t streamLoad4(const void *src)
+{
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+    return v;
 }
 __device__ __forceinline__ void streamStore4(uint32_t writeThrough, void *dst, uint32_t a)
 {

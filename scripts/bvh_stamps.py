@@ -13,7 +13,10 @@ from madrona_renderer_amd import scenes
 from tests import meshes
 cubes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 worlds = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-desc = meshes.cube_field(worlds, cubes, textured=os.environ.get('TEXTURED') == '1')
+if cubes > 0:
+    desc = meshes.cube_field(worlds, cubes, textured=os.environ.get('TEXTURED') == '1')
+else:           # cubes = 0: the BASELINE configs[4] shape (256x256 Raytracer, textured cube + plane), `worlds` views
+    desc = scenes.synthetic_scene(worlds, width=256, height=256, textured=True, render_mode="Raytracer")
 r = scenes.make_renderer(desc)
 print('%.1f us/step' % (r.time_renders(100) / 100 * 1000))
 for _ in range(5):
@@ -22,7 +25,8 @@ r.sync()
 lib = pkg.load_capi()
 lib.mrx_debug_stamps.restype = ctypes.c_int64
 lib.mrx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
-buf = np.zeros(worlds * 4 * 8, np.uint64)
+tiles = ((desc.width + 63) // 64) * ((desc.height + 63) // 64) if cubes == 0 else 1
+buf = np.zeros(worlds * tiles * 4 * 8, np.uint64)
 n = lib.mrx_debug_stamps(ctypes.c_void_p(r.native_handle()), buf.ctypes.data, buf.size)
 st = buf[:n].reshape(-1, 4, 8).astype(np.int64)
 t0 = st[:, :, 0].min()

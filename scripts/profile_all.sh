@@ -11,7 +11,7 @@ run() {  # name, steps, bench args
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return 0; fi
   echo "== $name: $*"
   STEPS="$steps" BENCH_ARGS="$*" bash "$GRAFT_REPO_ROOT/scripts/profile_round.sh" "${R}_${name}" > "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}.log" 2>&1 || tail -5 "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}.log"
-  python3 "$GRAFT_REPO_ROOT/bench.py" --steps "$steps" --warmup 200 --no-extra --no-cpu-baseline "$@" > "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}/bench.json" 2>/dev/null || true
+  python3 "$GRAFT_REPO_ROOT/bench.py" --steps "$steps" --warmup 200 --no-extra --no-cpu-baseline --no-strong "$@" > "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}/bench.json" 2>/dev/null || true
   tail -2 "$GRAFT_REPO_ROOT/gpurun_out/${R}_${name}.log" | cut -c1-600
 }
 run hl 2000

@@ -11,7 +11,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 STEPS="${STEPS:-2000}"
 # BENCH_ARGS selects another configuration, e.g. "--worlds 4096 --width 128 --height 128 --wall"
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 200 --no-cpu-baseline --no-extra ${BENCH_ARGS:-}"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 200 --no-cpu-baseline --no-extra --no-strong ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmcw" -- $BENCH > /dev/null 2> "$OUT/pmcw.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmcf" -- $BENCH > /dev/null 2> "$OUT/pmcf.log"
