@@ -63,6 +63,16 @@ public:
             uint32_t numCameras;
             Sim::WorldInit *worlds;
         } rcfg;
+
+        // ---- additions (trailing, defaulted: the reference's initialisers keep compiling) ----
+        // Single-process multi-device: with numDevices > 1 this one Manager spans deviceIDs[0 ..
+        // numDevices) -- the worlds are split into contiguous ranges, one shard (own tensors, own
+        // launch) per listed device, step() launches on all of them; gpuID is then ignored.
+        const int *deviceIDs = nullptr;
+        uint32_t numDevices = 0;
+        // Rows per world at least (the reference's maxInstancesPerWorld, src/mgr.cpp:378-388):
+        // spare rows start hidden and unbound, see refreshObjects().
+        uint32_t maxInstancesPerWorld = 0;
     };
 
     // Aborts (FATAL-style, like the reference) when construction fails.
@@ -73,25 +83,35 @@ public:
     void render();   // the render half of step()
     void sync();     // wait for everything enqueued so far
 
-    madrona::py::Tensor rgbTensor() const;
-    madrona::py::Tensor depthTensor() const;
-    madrona::py::Tensor segmaskTensor() const;
+    // (the tensor getters take the shard of a multi-device Manager; a Manager of one device
+    // has shard 0 only, so the reference's argument-less calls are unchanged)
+    madrona::py::Tensor rgbTensor(uint32_t shard = 0) const;
+    madrona::py::Tensor depthTensor(uint32_t shard = 0) const;
+    madrona::py::Tensor segmaskTensor(uint32_t shard = 0) const;
 
-    madrona::py::Tensor instancePositionTensor() const;
-    madrona::py::Tensor instanceRotationTensor() const;
+    madrona::py::Tensor instancePositionTensor(uint32_t shard = 0) const;
+    madrona::py::Tensor instanceRotationTensor(uint32_t shard = 0) const;
 
-    madrona::py::Tensor cameraPositionTensor() const;
-    madrona::py::Tensor cameraRotationTensor() const;
+    madrona::py::Tensor cameraPositionTensor(uint32_t shard = 0) const;
+    madrona::py::Tensor cameraRotationTensor(uint32_t shard = 0) const;
 
-    uint64_t rgbCudaPtr() const;
-    uint64_t depthCudaPtr() const;
-    uint64_t segmaskCudaPtr() const;
+    uint64_t rgbCudaPtr(uint32_t shard = 0) const;
+    uint64_t depthCudaPtr(uint32_t shard = 0) const;
+    uint64_t segmaskCudaPtr(uint32_t shard = 0) const;
 
     // Additions with no counterpart in the reference (measurement / tests).
-    madrona::py::Tensor visibilityTensor() const;   // needs MADRONA_MI355_VISIBILITY=1
+    madrona::py::Tensor visibilityTensor(uint32_t shard = 0) const;   // needs MADRONA_MI355_VISIBILITY=1
     // i32 [instances], mutable: negative hides the instance from the next step on
     // (the ObjectID column, src/sim.cpp:152-156; src/sim.inl:5-16)
-    madrona::py::Tensor instanceObjectTensor() const;
+    madrona::py::Tensor instanceObjectTensor(uint32_t shard = 0) const;
+    madrona::py::Tensor instanceScaleTensor(uint32_t shard = 0) const;
+    // binds every row to the (non-negative) object id its ObjectID column now holds: a spare
+    // row gets its geometry, an existing row swaps it (makeEntityRenderable at run time,
+    // src/sim.inl:5-8); waits for the device
+    void refreshObjects();
+    uint32_t numShards() const;                     // devices this Manager spans
+    // worlds [shardFirstWorld(i), shardFirstWorld(i + 1)) live on shard i
+    uint32_t shardFirstWorld(uint32_t shard) const;
     float timeRenders(int steps);                   // device ms for `steps` renders
     void mark(int which);                           // HIP event 0/1 on the stream
     float elapsedMs();                              // event1 - event0, waits for 1

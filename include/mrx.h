@@ -19,13 +19,14 @@
 #ifndef MRX_H
 #define MRX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MRX_ABI_VERSION 2
+#define MRX_ABI_VERSION 3
 
 enum {
     MRX_OK = 0,
@@ -119,7 +120,23 @@ typedef struct {
     int32_t kernel_variant;     /* 0 = default (raster kernels up to 128 triangles per
                                  * world, BVH path from 129); 1 = brute-force cross-check;
                                  * 2 = BVH path always; 3 = raster kernels always */
+    /* -- ABI 3 (a caller that sets struct_size = MRX_CONFIG_V2_SIZE passes none of these) --
+     * Single-process multi-device: with num_devices > 1 the renderer spans device_ids[0 ..
+     * num_devices): the worlds are split into contiguous ranges (sizes differ by at most one,
+     * as scenes.shard_range), one shard per listed device -- its own tensors, launched on that
+     * device's null stream -- and mrx_step launches on all of them.  gpu_id is then ignored;
+     * an id may repeat (several shards on one device).  The reference has a single gpuID
+     * (/root/reference/src/mgr.hpp:50) and every caller constructs ONE Manager
+     * (scripts/test.py:112-130, src/bindings.cpp:183-205): this is that constructor, wider. */
+    const int32_t *device_ids;
+    uint32_t num_devices;       /* 0 or 1: one device, gpu_id */
+    /* Rows per world at least (0 = exactly num_instances of each world): the reference sizes
+     * its renderer by maxInstancesPerWorld (/root/reference/src/mgr.cpp:378-388) and creates
+     * renderables at run time (src/sim.inl:5-8).  Spare rows start hidden and unbound
+     * (ObjectID -1, identity pose); see mrx_refresh_objects. */
+    uint32_t max_instances_per_world;
 } mrx_config;
+#define MRX_CONFIG_V2_SIZE ((uint32_t)offsetof(mrx_config, device_ids))
 
 typedef struct mrx_renderer mrx_renderer;
 
@@ -142,7 +159,8 @@ enum {
      * the sign is interpreted: the geometry an instance draws is bound when the
      * renderer is created, triangle slots / visibility ids stay where they are, and
      * the segmask shows the id of the bound object (label and geometry always agree:
-     * writing a different non-negative id changes neither). */
+     * writing a different non-negative id changes neither) -- until
+     * mrx_refresh_objects() re-binds the rows to the ids the column holds. */
     MRX_BUF_INSTANCE_OBJECT = 9,
     MRX_NUM_BUFFERS = 10
 };
@@ -161,6 +179,7 @@ typedef struct {
     uint32_t bvh_nodes;             /* 8-wide BLAS nodes of all objects     */
     uint32_t bvh_depth;             /* deepest BLAS                         */
     uint32_t max_world_instances;   /* most instances any one world holds   */
+    uint32_t num_shards;            /* devices the renderer spans (1 unless device_ids) */
 } mrx_info_t;
 
 /* -- lifetime: replaces Manager::Manager / ~Manager (mgr.cpp:505-527).
@@ -185,6 +204,32 @@ void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim,
  *    bytes of a buffer to host memory (what /root/reference/src/dump.cpp:53-70
  *    does with cudaMemcpy). */
 int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes);
+
+/* -- re-binding (makeEntityRenderable at run time, /root/reference/src/sim.inl:5-8): reads
+ *    the ObjectID column back and binds every row whose id is non-negative and differs from
+ *    the object it draws to that object -- a spare row (max_instances_per_world) gets its
+ *    geometry this way, an existing row swaps it.  Rows holding a negative id stay bound to
+ *    what they drew (hidden).  World-local triangle indices (visibility ids) are renumbered in
+ *    row order; the kernel and its launch shape are chosen again for the new triangle counts.
+ *    Waits for the stream; pose tensors and outputs keep their addresses. */
+int mrx_refresh_objects(mrx_renderer *r);
+
+/* -- shards (device_ids): mrx_num_shards = devices the renderer spans; mrx_shard returns shard i
+ *    as a renderer of its own -- valid with every function here until the parent is destroyed
+ *    (never destroy a shard) -- whose tensors hold its world range; mrx_buffer_shard is
+ *    mrx_buffer(mrx_shard(r, i), ...).  On a renderer of several shards mrx_step / mrx_render /
+ *    mrx_sync / mrx_refresh_objects / mrx_time_renders act on all of them, mrx_info adds up,
+ *    and mrx_buffer / mrx_copy_to_host / mrx_set_stream want a shard (MRX_E_UNSUPPORTED). */
+int mrx_num_shards(mrx_renderer *r);
+mrx_renderer *mrx_shard(mrx_renderer *r, int shard);
+void *mrx_buffer_shard(mrx_renderer *r, int shard, int which, int64_t dims[4], int *ndim,
+                       int *dtype, int *device);
+/*    first world of shard i in the renderer's world order (shard i owns worlds
+ *    [mrx_shard_first_world(i), mrx_shard_first_world(i + 1)); i = num_shards gives num_worlds) */
+int64_t mrx_shard_first_world(mrx_renderer *r, int shard);
+/*    the split itself (host only, no renderer needed): first world of shard `shard` of
+ *    `num_shards` over `num_worlds` worlds; shard = num_shards gives num_worlds */
+int64_t mrx_shard_split(uint32_t num_worlds, uint32_t shard, uint32_t num_shards);
 
 int mrx_info(mrx_renderer *r, mrx_info_t *out);
 void *mrx_stream(mrx_renderer *r);

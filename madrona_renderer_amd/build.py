@@ -82,7 +82,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         # (the BVH kernel's in-kernel stamps and phase switches: scripts/bvh_stamps.py, bvh_ablate.py)
         cmd += os.environ.get("MRX_EXTRA_HIPCC_FLAGS", "").split()
         cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
-        cmd += ["-lz", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+        cmd += ["-lz", "-ldl", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
         _run(cmd, verbose)
     return out
 
@@ -126,7 +126,30 @@ def build_headless(force=False, verbose=False):
                "-DMRX_DATA_DIR=\"%s\"" % os.path.join(ROOT, "data"),
                os.path.join(CSRC, "headless.cpp"), os.path.join(CSRC, "manager.cpp"),
                os.path.join(CSRC, "assets.cpp"), os.path.join(CSRC, "ktx2.cpp"),
-               "-L" + HERE, "-lmrx_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", out]
+               "-L" + HERE, "-lmrx_hip", "-lz", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", out]
+        _run(cmd, verbose)
+    return out
+
+
+def asan_driver_path():
+    return os.path.join(ROOT, "build", "host_asan_driver")
+
+
+def build_asan(force=False, verbose=False):
+    """AddressSanitizer + UBSan build of the host code that reads untrusted input (OBJ / MTL /
+    PNG / KTX2 / BC7 readers, BLAS builder) with its driver, csrc/host_asan_driver.cpp.  Host
+    compiler only (the HIP runtime header bvh.hpp pulls in is declarations); run by
+    tests/test_sanitizers.py on the CPU -- never on the GPU box."""
+    out = asan_driver_path()
+    srcs = ["host_asan_driver.cpp", "assets.cpp", "ktx2.cpp", "bvh.cpp"]
+    deps = srcs + ["assets.hpp", "bvh.hpp", "raster.hpp", "bc7_tables.inc"]
+    if force or _stale(out, deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address,undefined",
+               "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+               "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+        cmd += [os.path.join(CSRC, s) for s in srcs]
+        cmd += ["-lz", "-ldl", "-o", out]
         _run(cmd, verbose)
     return out
 
@@ -140,4 +163,7 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))
+    if "--asan" in sys.argv:
+        print(build_asan(force="--force" in sys.argv, verbose=True))
+    else:
+        print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))

@@ -56,6 +56,19 @@ std::string dirOf(const std::string &path)
     return slash == std::string::npos ? std::string() : path.substr(0, slash + 1);
 }
 
+// Text files are parsed line by line in place: bytes that would end the C string early (an
+// embedded NUL -- found by the sanitizer run over damaged files: strchr() then returned no
+// line end) become blanks, a final newline is added, and every line is terminated for the
+// time it is parsed, so that strtod / strtol can never run on into the next line.
+void prepareText(std::vector<uint8_t> &file)
+{
+    for (uint8_t &c : file)
+        if (c == 0)
+            c = ' ';
+    file.push_back('\n');
+    file.push_back(0);
+}
+
 // rest of the line, trimmed
 std::string restOfLine(const char *p, const char *eol)
 {
@@ -72,8 +85,7 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
     std::vector<uint8_t> file;
     if (!readFile(path, file, err))
         return false;
-    file.push_back('\n');
-    file.push_back(0);
+    prepareText(file);
 
     std::vector<float> vs, vts;
     std::vector<Corner> corners;
@@ -86,10 +98,14 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
     int32_t curMtl = -1;
 
     const char *p = (const char *)file.data();
+    const char *const fileEnd = p + file.size() - 1;      // the terminating NUL
     int lineNo = 0;
-    while (*p) {
+    while (p < fileEnd) {
         ++lineNo;
-        const char *eol = std::strchr(p, '\n');
+        char *eol = const_cast<char *>((const char *)std::memchr(p, '\n', (size_t)(fileEnd - p)));
+        if (!eol)
+            break;
+        *eol = 0;                                         // the line is a C string of its own
         skipSpace(p);
         if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
             p += 1;
@@ -109,7 +125,7 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
             const int nv = (int)(vs.size() / 3), nt = (int)(vts.size() / 2);
             while (true) {
                 skipSpace(p);
-                if (p >= eol || *p == '\n')
+                if (p >= eol || *p == 0)
                     break;
                 char *end = nullptr;
                 long vi = std::strtol(p, &end, 10);
@@ -154,7 +170,7 @@ bool loadOBJ(const std::string &path, TriSoup &out, std::string &err)
                 }
                 out.triMtl.push_back(curMtl);
             }
-        } else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t' || p[1] == '\r' || p[1] == '\n')) {
+        } else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t' || p[1] == '\r' || p[1] == 0)) {
             // a new object opens here unless the current one has no face yet
             if (out.numTris() > out.objStart.back())
                 out.objStart.push_back(out.numTris());
@@ -183,11 +199,14 @@ bool loadMTL(const std::string &path, std::vector<MtlMaterial> &out, std::string
     std::vector<uint8_t> file;
     if (!readFile(path, file, err))
         return false;
-    file.push_back('\n');
-    file.push_back(0);
+    prepareText(file);
     const char *p = (const char *)file.data();
-    while (*p) {
-        const char *eol = std::strchr(p, '\n');
+    const char *const fileEnd = p + file.size() - 1;
+    while (p < fileEnd) {
+        char *eol = const_cast<char *>((const char *)std::memchr(p, '\n', (size_t)(fileEnd - p)));
+        if (!eol)
+            break;
+        *eol = 0;
         skipSpace(p);
         if (!std::strncmp(p, "newmtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
             out.emplace_back();

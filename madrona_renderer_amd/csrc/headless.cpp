@@ -7,10 +7,11 @@
 //                     [--scene synthetic|demo] [--depth] [--gpus N]
 //
 // --gpus N (no counterpart upstream: the reference has a single gpuID,
-// mgr.hpp:50) shards the worlds over N devices of the node: one host thread
-// and one Manager per device, contiguous world ranges whose sizes differ by at
-// most one, no exchange between the devices.  A line per device and the two
-// reference lines for the whole node are printed.
+// mgr.hpp:50) renders the worlds on N devices of the node through ONE Manager
+// (Config::deviceIDs): contiguous world ranges whose sizes differ by at most
+// one, one shard per device, step() launches on all of them, no exchange
+// between the devices.  A line per device and the two reference lines for the
+// whole node are printed.
 //
 // It steps the renderer NUM_STEPS times, prints the reference's two lines
 // (`FPS`, `Average total step time`) and optionally writes the last frame of
@@ -18,14 +19,12 @@
 // a scene (headless.cpp:48-55 passes no rcfg); here the scene is either the
 // synthetic cube+plane worlds of the benchmark or the reference's demo scene
 // (viewer.cpp:74-164 / scripts/test.py:11-130).
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/madrona_mi355/manager.hpp"
@@ -202,12 +201,12 @@ void buildDemo(Scene &s, uint32_t n, const std::string &dataDir)
 // Tiled dump, as /root/reference/src/dump.cpp:45-119: ceil(sqrt(N)) rows of
 // images; depth as grey 255 * min(d / 255, 1).  Raytracer storage is [x][y]
 // and is transposed back (dump.cpp:9-21); rasterizer storage is row-major.
-bool dumpTiled(const std::string &name, Manager &mgr, uint32_t numImages, uint32_t resX,
+bool dumpTiled(const std::string &name, mrx_renderer *shard, uint32_t numImages, uint32_t resX,
                uint32_t resY, bool depth, bool transpose)
 {
     const size_t bytesPerImage = (size_t)4 * resX * resY;
     std::vector<uint8_t> host(bytesPerImage * numImages);
-    if (mrx_copy_to_host((mrx_renderer *)mgr.nativeHandle(), depth ? MRX_BUF_DEPTH : MRX_BUF_RGB,
+    if (mrx_copy_to_host(shard, depth ? MRX_BUF_DEPTH : MRX_BUF_RGB,
                          host.data(), host.size()) != MRX_OK) {
         std::fprintf(stderr, "%s\n", mrx_last_error());
         return false;
@@ -242,37 +241,36 @@ bool dumpTiled(const std::string &name, Manager &mgr, uint32_t numImages, uint32
     return true;
 }
 
-// [lo, hi) of the worlds device `rank` of `n` renders: contiguous, sizes differ by <= 1
-// (the same split as madrona_renderer_amd/scenes.py shard_range)
-void shardRange(uint32_t worlds, uint32_t rank, uint32_t n, uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t base = worlds / n, rem = worlds % n;
-    lo = rank * base + (rank < rem ? rank : rem);
-    hi = lo + base + (rank < rem ? 1u : 0u);
-}
+}  // namespace
 
-struct Shard {
-    uint32_t lo = 0, hi = 0;
-    int gpu = 0;
-    double seconds = 0.0;
-    bool ok = false;
-};
-
-// One device's share of the job: its own scene rows, its own Manager, NUM_STEPS
-// steps between two rendezvous with the other devices' threads.
-void runShard(const Args &args, const std::string &dataDir, Shard &sh, std::atomic<uint32_t> &ready,
-              uint32_t parties, const std::string &dumpName)
+int main(int argc, char **argv)
 {
-    const uint32_t n = sh.hi - sh.lo;
+    const Args args = parse(argc, argv);
+    const char *dd = std::getenv("MADRONA_MI355_DATA");
+    const std::string dataDir = dd ? dd : MRX_DATA_DIR;
+    // MRX_HEADLESS_REHEARSAL=1: every shard on device 0 -- walks the N-device
+    // control flow on a one-GPU box (the numbers then mean nothing)
+    const char *reh = std::getenv("MRX_HEADLESS_REHEARSAL");
+    const bool rehearsal = reh && reh[0] == '1';
+    if (!rehearsal && (int)args.gpus > mrx_device_count()) {
+        std::fprintf(stderr, "--gpus %u but %d HIP device(s) visible\n", args.gpus, mrx_device_count());
+        return EXIT_FAILURE;
+    }
+
+    // the whole job's scene; ONE Manager spans the devices (Config::deviceIDs): it splits the
+    // worlds into contiguous ranges, one shard per device, and step() launches on all of them
     Scene s;
-    if (args.demo) buildDemo(s, n, dataDir);
-    else buildSynthetic(s, sh.lo, n, dataDir);
+    if (args.demo) buildDemo(s, args.numWorlds, dataDir);
+    else buildSynthetic(s, 0, args.numWorlds, dataDir);
     for (auto &p : s.paths) s.pathPtrs.push_back(p.c_str());
     for (auto &p : s.texPaths) s.texPtrs.push_back(p.c_str());
+    std::vector<int> devices(args.gpus);
+    for (uint32_t g = 0; g < args.gpus; ++g)
+        devices[g] = rehearsal ? 0 : (int)g;
 
     Manager::Config cfg {};
-    cfg.gpuID = sh.gpu;
-    cfg.numWorlds = n;
+    cfg.gpuID = devices[0];
+    cfg.numWorlds = args.numWorlds;
     cfg.renderMode = args.mode == Mode::Raycaster ? Manager::RenderMode::Raytracer
                                                   : Manager::RenderMode::Rasterizer;
     cfg.batchRenderViewWidth = args.width;
@@ -295,74 +293,48 @@ void runShard(const Args &args, const std::string &dataDir, Shard &sh, std::atom
     rc.cameras = s.cameras.data();
     rc.numCameras = (uint32_t)s.cameras.size();
     rc.worlds = s.worlds.data();
+    if (args.gpus > 1) {
+        cfg.deviceIDs = devices.data();
+        cfg.numDevices = args.gpus;
+    }
 
     Manager mgr(cfg);              // aborts (FATAL) on failure, like the reference
     mgr.sync();
-    // every device starts stepping together
-    ready.fetch_add(1);
-    while (ready.load() < parties)
-        std::this_thread::yield();
 
     const auto start = std::chrono::system_clock::now();
+    mgr.mark(0);                   // an event on every device's stream, for the per-device lines
     for (uint32_t i = 0; i < args.numSteps; ++i)
         mgr.step();
+    mgr.mark(1);
     mgr.sync();
     const auto end = std::chrono::system_clock::now();
-    sh.seconds = std::chrono::duration<double>(end - start).count();
+    const double seconds = std::chrono::duration<double>(end - start).count();
 
-    sh.ok = true;
-    if (args.dump) {
-        const bool rt = args.mode == Mode::Raycaster;
-        const uint32_t resY = rt ? args.width : args.height;
-        sh.ok = dumpTiled(dumpName, mgr, n, args.width, resY, args.dumpDepth, rt);
-    }
-}
-
-}  // namespace
-
-int main(int argc, char **argv)
-{
-    const Args args = parse(argc, argv);
-    const char *dd = std::getenv("MADRONA_MI355_DATA");
-    const std::string dataDir = dd ? dd : MRX_DATA_DIR;
-    // MRX_HEADLESS_REHEARSAL=1: every shard on device 0 -- walks the N-device
-    // control flow on a one-GPU box (the numbers then mean nothing)
-    const char *reh = std::getenv("MRX_HEADLESS_REHEARSAL");
-    const bool rehearsal = reh && reh[0] == '1';
-    if (!rehearsal && (int)args.gpus > mrx_device_count()) {
-        std::fprintf(stderr, "--gpus %u but %d HIP device(s) visible\n", args.gpus, mrx_device_count());
-        return EXIT_FAILURE;
-    }
-
-    std::vector<Shard> shards(args.gpus);
-    std::atomic<uint32_t> ready { 0 };
-    std::vector<std::thread> threads;
-    for (uint32_t g = 0; g < args.gpus; ++g) {
-        shardRange(args.numWorlds, g, args.gpus, shards[g].lo, shards[g].hi);
-        shards[g].gpu = rehearsal ? 0 : (int)g;
-        const std::string name = args.gpus == 1 ? args.outName : args.outName + ".gpu" + std::to_string(g);
-        threads.emplace_back(runShard, std::cref(args), std::cref(dataDir), std::ref(shards[g]),
-                             std::ref(ready), args.gpus, name);
-    }
-    for (auto &t : threads)
-        t.join();
-
-    double slowest = 0.0;
     bool ok = true;
-    for (uint32_t g = 0; g < args.gpus; ++g) {
-        const Shard &sh = shards[g];
-        ok = ok && sh.ok;
-        slowest = sh.seconds > slowest ? sh.seconds : slowest;
-        if (args.gpus > 1)
-            std::printf("GPU %d: worlds [%u, %u) FPS %f\n", sh.gpu, sh.lo, sh.hi,
-                        (double)args.numSteps * (double)(sh.hi - sh.lo) / sh.seconds);
+    mrx_renderer *top = (mrx_renderer *)mgr.nativeHandle();
+    for (uint32_t g = 0; g < mgr.numShards(); ++g) {
+        const uint32_t lo = mgr.shardFirstWorld(g), hi = mgr.shardFirstWorld(g + 1);
+        mrx_renderer *sh = mrx_shard(top, (int)g);
+        if (args.gpus > 1) {
+            float ms = 0.0f;
+            if (mrx_elapsed_ms(sh, &ms) != MRX_OK || !(ms > 0.0f))
+                ms = (float)(seconds * 1000.0);
+            std::printf("GPU %d: worlds [%u, %u) FPS %f\n", devices[g], lo, hi,
+                        (double)args.numSteps * (double)(hi - lo) / (ms * 1e-3));
+        }
+        if (args.dump) {
+            const bool rt = args.mode == Mode::Raycaster;
+            const uint32_t resY = rt ? args.width : args.height;
+            const std::string name = args.gpus == 1 ? args.outName : args.outName + ".gpu" + std::to_string(g);
+            ok = dumpTiled(name, sh, hi - lo, args.width, resY, args.dumpDepth, rt) && ok;
+        }
     }
     if (!ok)
         return EXIT_FAILURE;
-    // whole node: every world of the job over the slowest device's time
-    const double fps = (double)args.numSteps * (double)args.numWorlds / slowest;
+    // whole node: every world of the job over the time all devices took
+    const double fps = (double)args.numSteps * (double)args.numWorlds / seconds;
     std::printf("FPS %f\n", fps);
     std::printf("Average total step time: %f ms\n",
-                1000.0 * slowest / (double)(args.numSteps ? args.numSteps : 1));
+                1000.0 * seconds / (double)(args.numSteps ? args.numSteps : 1));
     return 0;
 }

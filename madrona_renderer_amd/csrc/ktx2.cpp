@@ -8,15 +8,21 @@
 // the Khronos Data Format Specification ("BPTC compressed texture image
 // formats").  Supported: vkFormat BC7_UNORM / BC7_SRGB (145 / 146) and
 // R8G8B8A8_UNORM / _SRGB (37 / 43), 2D, one layer, one face, base level;
-// supercompression none or ZLIB (scheme 3).  Files whose payload is Basis
-// Universal (BasisLZ scheme 1 or UASTC, vkFormat 0) need a transcoder and are
-// refused with a message saying so.  sRGB formats are read as they are (the
+// supercompression none, Zstandard (scheme 2, through the system's libzstd) or
+// ZLIB (scheme 3).  Files whose payload is Basis Universal (BasisLZ scheme 1 or
+// UASTC, vkFormat 0) need a transcoder and are refused with a message saying so
+// (the UASTC / ETC1S block formats are defined by tables -- mode layouts,
+// partition maps, BISE sequences -- that are neither in this image nor checkable
+// here without a Basis encoder or a reference file; a decoder written from
+// memory that could not be validated would be worse than the refusal).  sRGB formats are read as they are (the
 // PNG path applies no transfer function either).
 #include "assets.hpp"
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 namespace mrx {
@@ -160,6 +166,36 @@ inline uint32_t le32(const uint8_t *p)
 }
 inline uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
 
+// size_t ZSTD_decompress(void *dst, size_t dstCapacity, const void *src, size_t compressedSize)
+// and unsigned ZSTD_isError(size_t) of libzstd.so.1 (stable since zstd 1.0), bound once.
+bool zstdDecompress(uint8_t *dst, size_t need, const uint8_t *src, size_t len, std::string &err)
+{
+    typedef size_t (*DecompressFn)(void *, size_t, const void *, size_t);
+    typedef unsigned (*IsErrorFn)(size_t);
+    static DecompressFn decompress = nullptr;
+    static IsErrorFn isError = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            decompress = (DecompressFn)dlsym(h, "ZSTD_decompress");
+            isError = (IsErrorFn)dlsym(h, "ZSTD_isError");
+        }
+    });
+    if (!decompress || !isError) {
+        err = "KTX2: Zstandard payload, but libzstd.so.1 is not installed";
+        return false;
+    }
+    const size_t got = decompress(dst, need, src, len);
+    if (isError(got) || got != need) {
+        err = "KTX2: Zstandard payload does not decompress to the image size";
+        return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 bool decodeKTX2Mem(const uint8_t *data, size_t size, Image &out, std::string &err)
@@ -186,8 +222,8 @@ bool decodeKTX2Mem(const uint8_t *data, size_t size, Image &out, std::string &er
         err = "KTX2: unsupported vkFormat " + std::to_string(vkFormat) + " (BC7 and R8G8B8A8 are read)";
         return false;
     }
-    if (scheme != 0 && scheme != 3) {
-        err = "KTX2: unsupported supercompression scheme " + std::to_string(scheme) + " (none and ZLIB are read)";
+    if (scheme != 0 && scheme != 2 && scheme != 3) {
+        err = "KTX2: unsupported supercompression scheme " + std::to_string(scheme) + " (none, Zstandard and ZLIB are read)";
         return false;
     }
     if ((size_t)80 + 24 * (size_t)(levels ? levels : 1) > size) {
@@ -204,7 +240,14 @@ bool decodeKTX2Mem(const uint8_t *data, size_t size, Image &out, std::string &er
     const size_t need = bc7 ? (size_t)bw * bh * 16 : (size_t)width * height * 4;
     std::vector<uint8_t> inflated;
     const uint8_t *src = data + off;
-    if (scheme == 3) {
+    if (scheme == 2) {
+        // Zstandard (what `toktx --zcmp` and the Basis tools write for non-Basis payloads): the
+        // system's libzstd, looked up at run time -- the image ships the library without its header
+        inflated.resize(need);
+        if (!zstdDecompress(inflated.data(), need, src, (size_t)len, err))
+            return false;
+        src = inflated.data();
+    } else if (scheme == 3) {
         inflated.resize(need);
         uLongf got = (uLongf)need;
         if (uncompress(inflated.data(), &got, src, (uLong)len) != Z_OK || got != need) {

@@ -37,11 +37,11 @@ struct Manager::Impl {
     mrx_renderer *r = nullptr;
     ~Impl() { mrx_destroy(r); }
 
-    Tensor wrap(int which) const
+    Tensor wrap(int which, uint32_t shard) const
     {
         int64_t dims[4] = { 0, 0, 0, 0 };
         int ndim = 0, dtype = 0, dev = 0;
-        void *p = mrx_buffer(r, which, dims, &ndim, &dtype, &dev);
+        void *p = mrx_buffer_shard(r, (int)shard, which, dims, &ndim, &dtype, &dev);
         if (!p)
             detail::fatal(mrx_last_error());
         TensorElementType t = dtype == MRX_DTYPE_U8 ? TensorElementType::UInt8
@@ -91,6 +91,9 @@ Manager::Manager(const Config &cfg)
     c.num_cameras = rc.numCameras;
     c.worlds = reinterpret_cast<const mrx_world_init *>(rc.worlds);
     c.stream = nullptr;
+    c.device_ids = cfg.deviceIDs;
+    c.num_devices = cfg.numDevices;
+    c.max_instances_per_world = cfg.maxInstancesPerWorld;
     // build-only knobs travel by environment so Config stays field-compatible
     if (const char *v = std::getenv("MADRONA_MI355_VISIBILITY"))
         if (std::atoi(v) != 0)
@@ -127,33 +130,50 @@ void Manager::sync()
         detail::fatal(mrx_last_error());
 }
 
-Tensor Manager::rgbTensor() const { return impl_->wrap(MRX_BUF_RGB); }
-Tensor Manager::depthTensor() const { return impl_->wrap(MRX_BUF_DEPTH); }
-Tensor Manager::segmaskTensor() const { return impl_->wrap(MRX_BUF_SEGMASK); }
-Tensor Manager::visibilityTensor() const { return impl_->wrap(MRX_BUF_VISIBILITY); }
+Tensor Manager::rgbTensor(uint32_t shard) const { return impl_->wrap(MRX_BUF_RGB, shard); }
+Tensor Manager::depthTensor(uint32_t shard) const { return impl_->wrap(MRX_BUF_DEPTH, shard); }
+Tensor Manager::segmaskTensor(uint32_t shard) const { return impl_->wrap(MRX_BUF_SEGMASK, shard); }
+Tensor Manager::visibilityTensor(uint32_t shard) const { return impl_->wrap(MRX_BUF_VISIBILITY, shard); }
 
-Tensor Manager::instanceObjectTensor() const { return impl_->wrap(MRX_BUF_INSTANCE_OBJECT); }
+Tensor Manager::instanceObjectTensor(uint32_t shard) const { return impl_->wrap(MRX_BUF_INSTANCE_OBJECT, shard); }
+Tensor Manager::instanceScaleTensor(uint32_t shard) const { return impl_->wrap(MRX_BUF_INSTANCE_SCALE, shard); }
 
-Tensor Manager::instancePositionTensor() const
+Tensor Manager::instancePositionTensor(uint32_t shard) const
 {
-    return impl_->wrap(MRX_BUF_INSTANCE_POSITION);
+    return impl_->wrap(MRX_BUF_INSTANCE_POSITION, shard);
 }
-Tensor Manager::instanceRotationTensor() const
+Tensor Manager::instanceRotationTensor(uint32_t shard) const
 {
-    return impl_->wrap(MRX_BUF_INSTANCE_ROTATION);
+    return impl_->wrap(MRX_BUF_INSTANCE_ROTATION, shard);
 }
-Tensor Manager::cameraPositionTensor() const
+Tensor Manager::cameraPositionTensor(uint32_t shard) const
 {
-    return impl_->wrap(MRX_BUF_CAMERA_POSITION);
+    return impl_->wrap(MRX_BUF_CAMERA_POSITION, shard);
 }
-Tensor Manager::cameraRotationTensor() const
+Tensor Manager::cameraRotationTensor(uint32_t shard) const
 {
-    return impl_->wrap(MRX_BUF_CAMERA_ROTATION);
+    return impl_->wrap(MRX_BUF_CAMERA_ROTATION, shard);
 }
 
-uint64_t Manager::rgbCudaPtr() const { return (uint64_t)rgbTensor().devicePtr(); }
-uint64_t Manager::depthCudaPtr() const { return (uint64_t)depthTensor().devicePtr(); }
-uint64_t Manager::segmaskCudaPtr() const { return (uint64_t)segmaskTensor().devicePtr(); }
+uint64_t Manager::rgbCudaPtr(uint32_t shard) const { return (uint64_t)rgbTensor(shard).devicePtr(); }
+uint64_t Manager::depthCudaPtr(uint32_t shard) const { return (uint64_t)depthTensor(shard).devicePtr(); }
+uint64_t Manager::segmaskCudaPtr(uint32_t shard) const { return (uint64_t)segmaskTensor(shard).devicePtr(); }
+
+void Manager::refreshObjects()
+{
+    if (mrx_refresh_objects(impl_->r) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
+uint32_t Manager::numShards() const { return (uint32_t)mrx_num_shards(impl_->r); }
+
+uint32_t Manager::shardFirstWorld(uint32_t shard) const
+{
+    const int64_t w = mrx_shard_first_world(impl_->r, (int)shard);
+    if (w < 0)
+        detail::fatal(mrx_last_error());
+    return (uint32_t)w;
+}
 
 float Manager::timeRenders(int steps)
 {

@@ -114,6 +114,17 @@ struct DevBuf {
             return e;
         return hipMemcpy(ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
+    // upload again after the host table changed (mrx_refresh_objects): in place when the size fits
+    hipError_t reupload(const std::vector<T> &h)
+    {
+        if (ptr && owned && h.size() <= count && !vmmSize) {
+            if (h.empty())
+                return hipSuccess;
+            return hipMemcpy(ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+        }
+        release();
+        return upload(h);
+    }
     void release()
     {
         if (base && owned && vmmSize) {
@@ -242,6 +253,17 @@ struct mrx_renderer {
     DevBuf<uint32_t> bvhLeafTris, worldInstStart, viewWorld, instKBase;
     DevBuf<mrx::ObjInfo> objInfo;
     bool useBvh = false;
+    // host copies the geometry binding is (re)built from (bindGeometry): the object each
+    // instance row is bound to, the world -> row and view -> world tables, the BLAS set
+    std::vector<int32_t> boundObj;
+    std::vector<uint32_t> worldInstStartHost, viewWorldHost, worldCams;
+    std::vector<mrx::TriMat> triMatsHost;
+    mrx::BlasSet blas;
+    uint32_t bvhMinTris = mrx::kBvhMinTris;
+    // single-process multi-device (mrx_config.device_ids): a renderer that only fans out to
+    // one sub-renderer per device, each owning a contiguous range of the worlds
+    std::vector<mrx_renderer *> shards;
+    std::vector<uint32_t> shardFirstWorld;      // [shards + 1]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // what choosePlacement measured (mrx_placement): us per render of every candidate
     // output allocation it timed, in order, and of the one it kept
@@ -267,6 +289,10 @@ struct mrx_renderer {
 
     ~mrx_renderer()
     {
+        for (mrx_renderer *sh : shards)
+            delete sh;
+        if (!shards.empty())
+            return;
         (void)hipSetDevice(device);
         tris.release(); triMats.release(); textures.release(); texels.release();
         viewTris.release(); viewTriCount.release();
@@ -372,12 +398,130 @@ void shellOrientation(const mrx::ObjTri *tris, uint32_t n, mrx::TriMat *mats)
     }
 }
 
+// Everything that follows from which object each instance row is bound to (r.boundObj):
+// the world-local triangle numbering, the per-view draw lists of the raster kernels, the
+// per-instance BLAS records of the BVH path, which kernel renders, the uniform-world fast
+// paths.  Runs at creation and again from mrx_refresh_objects; the pose tensors, the
+// outputs and the object pool are untouched.
+int bindGeometry(mrx_renderer &r)
+{
+    using namespace mrx;
+    const std::vector<int32_t> &bound = r.boundObj;
+    const std::vector<uint32_t> &worldInstStart = r.worldInstStartHost, &viewWorld = r.viewWorldHost;
+    const uint32_t numWorlds = (uint32_t)worldInstStart.size() - 1u;
+    auto drawn = [&](int32_t o) { return o >= 0 && (size_t)o < r.objFirst.size(); };
+    std::vector<uint32_t> worldTriStart(1, 0), instKBase(bound.size(), 0);
+    std::vector<WorldTri> worldTris;   // per world; expanded per view below
+    uint32_t maxWorldTris = 0;
+    for (uint32_t w = 0; w < numWorlds; ++w) {
+        for (uint32_t row = worldInstStart[w]; row < worldInstStart[w + 1]; ++row) {
+            // first world-local triangle index of the instance (the visibility id space)
+            instKBase[row] = (uint32_t)worldTris.size() - worldTriStart[w];
+            if (drawn(bound[row])) {
+                const uint32_t f = (uint32_t)r.objFirst[bound[row]];
+                const uint32_t n = (uint32_t)r.objCount[bound[row]];
+                for (uint32_t t = 0; t < n; ++t)
+                    worldTris.push_back(WorldTri { row, f + t });
+            }
+        }
+        worldTriStart.push_back((uint32_t)worldTris.size());
+        maxWorldTris = std::max(maxWorldTris, worldTriStart[w + 1] - worldTriStart[w]);
+    }
+    // Which kernel renders: the group kernel (raster.hip) wins while a world fits its
+    // 128-slot instantiation, the BVH path (bvh.hip) as soon as the 256-slot one
+    // would be needed (measured at 1024 worlds x 64x64: 122 triangles 20.9 against
+    // 25.7 us, 134 triangles 28.6 against 27.0, 482 triangles 83 against 31.4 --
+    // profiles/r02_bvh_crossover.txt); it serves both render modes.
+    // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH /
+    // the raster kernels.
+    r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= r.bvhMinTris);
+    if (r.useBvh && maxWorldTris > kBvhMaxWorldTris)
+        return fail(MRX_E_UNSUPPORTED, "more than 2M triangles in one world");
+    // per-view draw lists with a fixed stride (one load level in the kernel);
+    // the BVH path walks the world's instances instead and needs none
+    const uint32_t stride = maxWorldTris ? maxWorldTris : 1u;
+    {
+        const size_t nv = r.useBvh ? 0 : viewWorld.size();
+        std::vector<WorldTri> viewTris(nv * stride, WorldTri { 0, 0 });
+        std::vector<uint32_t> viewTriCount(nv);
+        for (size_t v = 0; v < nv; ++v) {
+            const uint32_t w = viewWorld[v];
+            const uint32_t b = worldTriStart[w], n = worldTriStart[w + 1] - b;
+            viewTriCount[v] = n;
+            std::memcpy(viewTris.data() + v * stride, worldTris.data() + b, n * sizeof(WorldTri));
+        }
+        MRX_HIP(r.viewTris.reupload(viewTris));
+        MRX_HIP(r.viewTriCount.reupload(viewTriCount));
+    }
+    // per instance: range, root and box of its bound object, so the per-step TLAS build has
+    // no load that depends on another
+    std::vector<ObjInfo> instInfo(bound.size());
+    for (size_t i = 0; i < bound.size(); ++i) {
+        ObjInfo info {};
+        info.root = -1;
+        if (drawn(bound[i]))
+            info = r.blas.objects[bound[i]];
+        instInfo[i] = info;
+    }
+    if (instInfo.empty())
+        instInfo.emplace_back();                      // idle lanes read row 0
+    MRX_HIP(r.objInfo.reupload(instInfo));
+    MRX_HIP(r.instKBase.reupload(instKBase));
+
+    RasterParams &p = r.params;
+    p.anyTextured = 0;
+    for (const mrx::WorldTri &wt : worldTris)
+        if (r.triMatsHost[wt.tri].tex >= 0) {
+            p.anyTextured = 1;
+            break;
+        }
+    p.viewTris = r.viewTris.ptr;
+    p.viewTriCount = r.viewTriCount.ptr;
+    p.viewTriStride = stride;
+    p.instInfo = r.objInfo.ptr;
+    p.instKBase = r.instKBase.ptr;
+    // uniform worlds -> arithmetic draw list (raster.hpp): every world the same 1..4 bound
+    // objects in the same order, the same camera count
+    p.uniInstances = 0;
+    p.uniCamsPerWorld = 0;
+    if (numWorlds > 0) {
+        const uint32_t n0 = worldInstStart[1] - worldInstStart[0], c0 = r.worldCams[0];
+        bool uni = n0 >= 1 && n0 <= 4 && c0 >= 1;
+        for (uint32_t w = 0; uni && w < numWorlds; ++w) {
+            uni = worldInstStart[w + 1] - worldInstStart[w] == n0 && r.worldCams[w] == c0;
+            for (uint32_t i = 0; uni && i < n0; ++i) {
+                const int32_t oa = bound[worldInstStart[w] + i], ob = bound[worldInstStart[0] + i];
+                uni = oa == ob && drawn(oa);
+            }
+        }
+        if (uni) {
+            p.uniInstances = n0;
+            p.uniCamsPerWorld = c0;
+            uint32_t acc = 0;
+            for (uint32_t i = 0; i < 4; ++i) {
+                p.uniPrefix[i] = acc;
+                p.uniFirstTri[i] = 0;
+                if (i < n0) {
+                    const int32_t o = bound[worldInstStart[0] + i];
+                    p.uniFirstTri[i] = (uint32_t)r.objFirst[o];
+                    acc += (uint32_t)r.objCount[o];
+                }
+            }
+            p.uniPrefix[4] = acc;
+        }
+    }
+    r.info.max_world_triangles = maxWorldTris;
+    r.info.render_path = r.useBvh ? 1 : 0;
+    return MRX_OK;
+}
+
 int buildScene(const mrx_config &cfg, mrx_renderer &r)
 {
     using namespace mrx;
     // ---- objects: disk assets in path order, then one object per raw mesh
     //      (/root/reference/src/mgr.cpp:267-270, scripts/test.py:7-10)
     std::vector<ObjTri> &tris = r.hostTris;
+    const uint32_t maxInstancesPerWorld = cfg.max_instances_per_world;
     auto appendObject = [&](const float *pos, const float *uv, uint32_t n, int32_t mat) {
         r.objFirst.push_back((int32_t)tris.size());
         r.objCount.push_back((int32_t)n);
@@ -549,40 +693,43 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
                          triMats.data() + r.objFirst[o]);
 
     // ---- world assembly: per-world copies of the table rows, world-major
-    //      (/root/reference/src/sim.cpp:143-175)
+    //      (/root/reference/src/sim.cpp:143-175).  With max_instances_per_world a world owns
+    //      that many rows at least (the reference sizes its renderer by maxInstancesPerWorld,
+    //      src/mgr.cpp:378-388, and creates renderables at run time, src/sim.inl:5-8): the
+    //      spare rows start hidden and unbound (ObjectID -1, identity pose) and are bound to
+    //      an object by writing its id and calling mrx_refresh_objects.
     std::vector<float> instPos, instRot, instScale, camPos, camRot;
     std::vector<int32_t> instObj;
-    std::vector<uint32_t> worldTriStart(1, 0), viewWorld;
-    std::vector<uint32_t> worldInstStart(1, 0), instKBase;
-    std::vector<WorldTri> worldTris;   // per world; expanded per view below
-    uint32_t maxWorldTris = 0, maxWorldInst = 0;
+    std::vector<uint32_t> &worldInstStart = r.worldInstStartHost, &viewWorld = r.viewWorldHost;
+    worldInstStart.assign(1, 0u);
+    viewWorld.clear();
+    r.worldCams.clear();
+    uint32_t maxWorldInst = 0;
     for (uint32_t w = 0; w < cfg.num_worlds; ++w) {
         const mrx_world_init &wi = cfg.worlds[w];
         if ((uint64_t)wi.instances_offset + wi.num_instances > cfg.num_instances ||
             (uint64_t)wi.cameras_offset + wi.num_cameras > cfg.num_cameras)
             return fail(MRX_E_INVALID, "world " + std::to_string(w) +
                                            " addresses rows outside the tables");
-        for (uint32_t i = 0; i < wi.num_instances; ++i) {
-            const mrx_instance &in = cfg.instances[wi.instances_offset + i];
-            const uint32_t row = (uint32_t)instObj.size();
-            instPos.insert(instPos.end(), in.position, in.position + 3);
-            instRot.insert(instRot.end(), in.rotation, in.rotation + 4);
-            instScale.insert(instScale.end(), in.scale, in.scale + 3);
-            instObj.push_back(in.object_id);
-            // first world-local triangle index of the instance (the visibility id space)
-            instKBase.push_back((uint32_t)worldTris.size() - worldTriStart[w]);
-            if (in.object_id >= 0 && (size_t)in.object_id < r.objFirst.size()) {
-                const uint32_t f = (uint32_t)r.objFirst[in.object_id];
-                const uint32_t n = (uint32_t)r.objCount[in.object_id];
-                for (uint32_t t = 0; t < n; ++t)
-                    worldTris.push_back(WorldTri { row, f + t });
+        const uint32_t rows = std::max(wi.num_instances, maxInstancesPerWorld);
+        for (uint32_t i = 0; i < rows; ++i) {
+            if (i < wi.num_instances) {
+                const mrx_instance &in = cfg.instances[wi.instances_offset + i];
+                instPos.insert(instPos.end(), in.position, in.position + 3);
+                instRot.insert(instRot.end(), in.rotation, in.rotation + 4);
+                instScale.insert(instScale.end(), in.scale, in.scale + 3);
+                instObj.push_back(in.object_id);
+            } else {
+                const float zero[3] = { 0.f, 0.f, 0.f }, ident[4] = { 1.f, 0.f, 0.f, 0.f }, one[3] = { 1.f, 1.f, 1.f };
+                instPos.insert(instPos.end(), zero, zero + 3);
+                instRot.insert(instRot.end(), ident, ident + 4);
+                instScale.insert(instScale.end(), one, one + 3);
+                instObj.push_back(-1);
             }
         }
-        worldTriStart.push_back((uint32_t)worldTris.size());
         worldInstStart.push_back((uint32_t)instObj.size());
-        maxWorldInst = std::max(maxWorldInst, wi.num_instances);
-        const uint32_t nt = worldTriStart[w + 1] - worldTriStart[w];
-        maxWorldTris = nt > maxWorldTris ? nt : maxWorldTris;
+        maxWorldInst = std::max(maxWorldInst, rows);
+        r.worldCams.push_back(wi.num_cameras);
         for (uint32_t c = 0; c < wi.num_cameras; ++c) {
             const mrx_camera &cam = cfg.cameras[wi.cameras_offset + c];
             camPos.insert(camPos.end(), cam.position, cam.position + 3);
@@ -590,44 +737,21 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             viewWorld.push_back(w);
         }
     }
+    // the object each row draws: bound here, re-bound by mrx_refresh_objects
+    r.boundObj = instObj;
 
-    // ---- upload
+    // ---- upload what never changes shape
     MRX_HIP(r.tris.upload(tris));
     MRX_HIP(r.triMats.upload(triMats));
     MRX_HIP(r.textures.upload(texDescs));
     MRX_HIP(r.texels.upload(texels));
-    // Which kernel renders: the group kernel (raster.hip) wins while a world fits its
-    // 128-slot instantiation, the BVH path (bvh.hip) as soon as the 256-slot one
-    // would be needed (measured at 1024 worlds x 64x64: 122 triangles 20.9 against
-    // 25.7 us, 134 triangles 28.6 against 27.0, 482 triangles 83 against 31.4 --
-    // profiles/r02_bvh_crossover.txt); it serves both render modes.
-    // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH /
-    // the raster kernels.
-    uint32_t bvhMinTris = kBvhMinTris;
+    r.triMatsHost = triMats;
+    r.bvhMinTris = kBvhMinTris;
     if (const char *dbg = std::getenv("MRX_BVH_MIN_TRIS"))
-        bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
-    r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= bvhMinTris);
-    if (r.useBvh && maxWorldTris > kBvhMaxWorldTris)
-        return fail(MRX_E_UNSUPPORTED, "more than 2M triangles in one world");
-    // per-view draw lists with a fixed stride (one load level in the kernel);
-    // the BVH path walks the world's instances instead and needs none
-    const uint32_t stride = maxWorldTris ? maxWorldTris : 1u;
-    {
-        const size_t nv = r.useBvh ? 0 : viewWorld.size();
-        std::vector<WorldTri> viewTris(nv * stride, WorldTri { 0, 0 });
-        std::vector<uint32_t> viewTriCount(nv);
-        for (size_t v = 0; v < nv; ++v) {
-            const uint32_t w = viewWorld[v];
-            const uint32_t b = worldTriStart[w], n = worldTriStart[w + 1] - b;
-            viewTriCount[v] = n;
-            std::memcpy(viewTris.data() + v * stride, worldTris.data() + b, n * sizeof(WorldTri));
-        }
-        MRX_HIP(r.viewTris.upload(viewTris));
-        MRX_HIP(r.viewTriCount.upload(viewTriCount));
-    }
+        r.bvhMinTris = (uint32_t)std::max(0, std::atoi(dbg));
     // BLAS per object (the reference builds them at load too: mgr.cpp:472-473)
-    BlasSet blas;
-    buildBlas(tris.data(), r.objFirst, r.objCount, blas);
+    buildBlas(tris.data(), r.objFirst, r.objCount, r.blas);
+    const BlasSet &blas = r.blas;
     if (blas.leafTris.size() >= (1u << kBvhLeafStartBits))
         return fail(MRX_E_UNSUPPORTED, "too many triangles in BLAS leaves");
     // (the kernel's traversal stack is kBvhStackCap entries of LDS per wave: a deeper tree
@@ -636,24 +760,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     if (1 + 7 * blas.maxDepth > kBvhStackCap)
         return fail(MRX_E_UNSUPPORTED, "a BLAS is too deep for the traversal stack (" +
                                            std::to_string(blas.maxDepth) + " levels)");
-    // per instance: range, root and box of its (creation-time) object, so the
-    // per-step TLAS build has no load that depends on another
-    std::vector<ObjInfo> instInfo(instObj.size());
-    for (size_t i = 0; i < instObj.size(); ++i) {
-        ObjInfo info {};
-        info.root = -1;
-        if (instObj[i] >= 0 && (size_t)instObj[i] < blas.objects.size())
-            info = blas.objects[instObj[i]];
-        instInfo[i] = info;
-    }
-    if (instInfo.empty())
-        instInfo.emplace_back();                      // idle lanes read row 0
     MRX_HIP(r.bvhNodes.upload(blas.nodes));
     MRX_HIP(r.bvhLeafTris.upload(blas.leafTris));
-    MRX_HIP(r.objInfo.upload(instInfo));
     MRX_HIP(r.worldInstStart.upload(worldInstStart));
     MRX_HIP(r.viewWorld.upload(viewWorld));
-    MRX_HIP(r.instKBase.upload(instKBase));
     MRX_HIP(r.instPos.upload(instPos));
     MRX_HIP(r.instRot.upload(instRot));
     MRX_HIP(r.instScale.upload(instScale));
@@ -687,48 +797,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     RasterParams &p = r.params;
     p.tris = r.tris.ptr;
     p.triMats = r.triMats.ptr;
-    p.anyTextured = 0;
-    for (const mrx::WorldTri &wt : worldTris)
-        if (triMats[wt.tri].tex >= 0) {
-            p.anyTextured = 1;
-            break;
-        }
     p.textures = r.textures.ptr;
     p.texels = r.texels.ptr;
-    p.viewTris = r.viewTris.ptr;
-    p.viewTriCount = r.viewTriCount.ptr;
-    p.viewTriStride = stride;
-    // uniform worlds -> arithmetic draw list (raster.hpp)
-    p.uniInstances = 0;
-    p.uniCamsPerWorld = 0;
-    if (cfg.num_worlds > 0) {
-        const mrx_world_init &w0 = cfg.worlds[0];
-        bool uni = w0.num_instances >= 1 && w0.num_instances <= 4 && w0.num_cameras >= 1;
-        for (uint32_t w = 0; uni && w < cfg.num_worlds; ++w) {
-            const mrx_world_init &wi = cfg.worlds[w];
-            uni = wi.num_instances == w0.num_instances && wi.num_cameras == w0.num_cameras;
-            for (uint32_t i = 0; uni && i < wi.num_instances; ++i) {
-                const int32_t oa = cfg.instances[wi.instances_offset + i].object_id;
-                const int32_t ob = cfg.instances[w0.instances_offset + i].object_id;
-                uni = oa == ob && oa >= 0 && (size_t)oa < r.objFirst.size();
-            }
-        }
-        if (uni) {
-            p.uniInstances = w0.num_instances;
-            p.uniCamsPerWorld = w0.num_cameras;
-            uint32_t acc = 0;
-            for (uint32_t i = 0; i < 4; ++i) {
-                p.uniPrefix[i] = acc;
-                p.uniFirstTri[i] = 0;
-                if (i < w0.num_instances) {
-                    const int32_t o = cfg.instances[w0.instances_offset + i].object_id;
-                    p.uniFirstTri[i] = (uint32_t)r.objFirst[o];
-                    acc += (uint32_t)r.objCount[o];
-                }
-            }
-            p.uniPrefix[4] = acc;
-        }
-    }
     p.instPos = r.instPos.ptr;
     p.instRot = r.instRot.ptr;
     p.instScale = r.instScale.ptr;
@@ -811,22 +881,21 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         p.debugSlots = std::atoi(dbg);
     p.bvhNodes = r.bvhNodes.ptr;
     p.bvhLeafTris = r.bvhLeafTris.ptr;
-    p.instInfo = r.objInfo.ptr;
     p.numObjects = (uint32_t)r.objFirst.size();
     p.bvhUniInst = p.bvhUniCams = 0;
     if (cfg.num_worlds > 0) {
         bool uni = true;
+        const uint32_t rows0 = worldInstStart[1] - worldInstStart[0];
         for (uint32_t w = 1; uni && w < cfg.num_worlds; ++w)
-            uni = cfg.worlds[w].num_instances == cfg.worlds[0].num_instances &&
+            uni = worldInstStart[w + 1] - worldInstStart[w] == rows0 &&
                   cfg.worlds[w].num_cameras == cfg.worlds[0].num_cameras;
-        if (uni && cfg.worlds[0].num_instances > 0 && cfg.worlds[0].num_cameras > 0) {
-            p.bvhUniInst = cfg.worlds[0].num_instances;
+        if (uni && rows0 > 0 && cfg.worlds[0].num_cameras > 0) {
+            p.bvhUniInst = rows0;
             p.bvhUniCams = cfg.worlds[0].num_cameras;
         }
     }
     p.worldInstStart = r.worldInstStart.ptr;
     p.viewWorld = r.viewWorld.ptr;
-    p.instKBase = r.instKBase.ptr;
     // TLAS records of up to 128 instances stay in LDS at once (two workgroups
     // per CU); larger worlds take several passes
     p.bvhPassInst = std::min<uint32_t>(128u, std::max<uint32_t>(64u, (maxWorldInst + 63u) / 64u * 64u));
@@ -855,18 +924,17 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     inf.num_triangles = (uint32_t)tris.size();
     inf.num_materials = (uint32_t)allMats.size();
     inf.num_textures = (uint32_t)texDescs.size();
-    inf.max_world_triangles = maxWorldTris;
     inf.storage_fast = nfast;
     inf.storage_slow = nslow;
     inf.device_id = r.device;
     inf.kernel_variant = r.variant;
-    inf.render_path = r.useBvh ? 1 : 0;
     inf.bvh_nodes = (uint32_t)blas.nodes.size();
     inf.bvh_depth = blas.maxDepth;
     inf.max_world_instances = maxWorldInst;
+    inf.num_shards = 1;
     inf.bytes_per_step = (uint64_t)px * (wantIds ? 12u : 8u) +
                          44ull * inf.num_instances + 28ull * nviews;
-    return MRX_OK;
+    return bindGeometry(r);
 }
 
 }  // namespace
@@ -1014,46 +1082,25 @@ static int choosePlacement(mrx_renderer *r)
     return MRX_OK;
 }
 
-int mrx_create(const mrx_config *cfg, mrx_renderer **out)
+// one renderer on one device (mrx_create proper, or one shard of a multi-device renderer)
+static int createOne(const mrx_config &cfg, mrx_renderer **out)
 {
-    if (!cfg || !out)
-        return fail(MRX_E_INVALID, "null argument");
-    *out = nullptr;
-    if (cfg->struct_size != sizeof(mrx_config))
-        return fail(MRX_E_INVALID, "mrx_config size mismatch (ABI)");
-    if (cfg->render_mode != MRX_MODE_RASTERIZER && cfg->render_mode != MRX_MODE_RAYTRACER)
-        return fail(MRX_E_INVALID, "bad render_mode");
-    if (cfg->view_width == 0 || cfg->view_height == 0 || cfg->view_width > 16384 ||
-        cfg->view_height > 16384)
-        return fail(MRX_E_INVALID, "bad view size");
-    if (cfg->num_worlds && !cfg->worlds)
-        return fail(MRX_E_INVALID, "worlds is null");
-    if ((cfg->num_instances && !cfg->instances) || (cfg->num_cameras && !cfg->cameras) ||
-        (cfg->num_asset_paths && !cfg->asset_paths) || (cfg->num_materials && !cfg->materials) ||
-        (cfg->num_textures && !cfg->texture_paths))
-        return fail(MRX_E_INVALID, "a table pointer is null while its count is not zero");
-    if (cfg->geo.num_meshes &&
-        (!cfg->geo.vertices || !cfg->geo.uvs || !cfg->geo.indices || !cfg->geo.mesh_vertex_offsets ||
-         !cfg->geo.mesh_index_offsets || !cfg->geo.mesh_materials))
-        return fail(MRX_E_INVALID, "raw geometry arrays are null while num_meshes is not zero");
-    if (cfg->kernel_variant < 0 || cfg->kernel_variant >= mrx::kNumVariants)
-        return fail(MRX_E_INVALID, "bad kernel_variant");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MRX_E_NO_DEVICE,
                     "no HIP device: this library renders on MI355X only (no CPU path)");
-    if (cfg->gpu_id < 0 || cfg->gpu_id >= ndev)
-        return fail(MRX_E_NO_DEVICE, "gpu_id " + std::to_string(cfg->gpu_id) +
+    if (cfg.gpu_id < 0 || cfg.gpu_id >= ndev)
+        return fail(MRX_E_NO_DEVICE, "gpu_id " + std::to_string(cfg.gpu_id) +
                                          " out of range (" + std::to_string(ndev) + " devices)");
-    MRX_HIP(hipSetDevice(cfg->gpu_id));
+    MRX_HIP(hipSetDevice(cfg.gpu_id));
 
     mrx_renderer *r = new mrx_renderer();
-    r->device = cfg->gpu_id;
-    r->stream = (hipStream_t)cfg->stream;
-    r->mode = cfg->render_mode;
-    r->flags = cfg->flags;
-    r->variant = cfg->kernel_variant;
-    int rc = buildScene(*cfg, *r);
+    r->device = cfg.gpu_id;
+    r->stream = (hipStream_t)cfg.stream;
+    r->mode = cfg.render_mode;
+    r->flags = cfg.flags;
+    r->variant = cfg.kernel_variant;
+    int rc = buildScene(cfg, *r);
     if (rc == MRX_OK) {
         hipError_t e = hipEventCreate(&r->ev0);
         if (e == hipSuccess) e = hipEventCreate(&r->ev1);
@@ -1075,12 +1122,101 @@ int mrx_create(const mrx_config *cfg, mrx_renderer **out)
     return MRX_OK;
 }
 
+// contiguous world range of shard i of n: sizes differ by at most one (scenes.shard_range)
+static uint32_t shardFirstWorld(uint32_t numWorlds, uint32_t i, uint32_t n)
+{
+    const uint32_t base = numWorlds / n, rem = numWorlds % n;
+    return i * base + std::min(i, rem);
+}
+
+int mrx_create(const mrx_config *cfgIn, mrx_renderer **out)
+{
+    if (!cfgIn || !out)
+        return fail(MRX_E_INVALID, "null argument");
+    *out = nullptr;
+    // ABI 2 callers pass the struct without its trailing ABI 3 fields: those read as zero
+    if (cfgIn->struct_size != sizeof(mrx_config) && cfgIn->struct_size != MRX_CONFIG_V2_SIZE)
+        return fail(MRX_E_INVALID, "mrx_config size mismatch (ABI)");
+    mrx_config full;
+    std::memset(&full, 0, sizeof full);
+    std::memcpy(&full, cfgIn, cfgIn->struct_size);
+    full.struct_size = sizeof(mrx_config);
+    const mrx_config *cfg = &full;
+    if (cfg->render_mode != MRX_MODE_RASTERIZER && cfg->render_mode != MRX_MODE_RAYTRACER)
+        return fail(MRX_E_INVALID, "bad render_mode");
+    if (cfg->view_width == 0 || cfg->view_height == 0 || cfg->view_width > 16384 ||
+        cfg->view_height > 16384)
+        return fail(MRX_E_INVALID, "bad view size");
+    if (cfg->num_worlds && !cfg->worlds)
+        return fail(MRX_E_INVALID, "worlds is null");
+    if ((cfg->num_instances && !cfg->instances) || (cfg->num_cameras && !cfg->cameras) ||
+        (cfg->num_asset_paths && !cfg->asset_paths) || (cfg->num_materials && !cfg->materials) ||
+        (cfg->num_textures && !cfg->texture_paths))
+        return fail(MRX_E_INVALID, "a table pointer is null while its count is not zero");
+    if (cfg->geo.num_meshes &&
+        (!cfg->geo.vertices || !cfg->geo.uvs || !cfg->geo.indices || !cfg->geo.mesh_vertex_offsets ||
+         !cfg->geo.mesh_index_offsets || !cfg->geo.mesh_materials))
+        return fail(MRX_E_INVALID, "raw geometry arrays are null while num_meshes is not zero");
+    if (cfg->kernel_variant < 0 || cfg->kernel_variant >= mrx::kNumVariants)
+        return fail(MRX_E_INVALID, "bad kernel_variant");
+    if (cfg->max_instances_per_world > (1u << 20))
+        return fail(MRX_E_INVALID, "max_instances_per_world out of range");
+    if (cfg->num_devices > 1 && !cfg->device_ids)
+        return fail(MRX_E_INVALID, "device_ids is null while num_devices is not zero");
+    if (cfg->num_devices > 64)
+        return fail(MRX_E_INVALID, "more than 64 devices");
+    if (cfg->num_devices <= 1) {
+        if (cfg->num_devices == 1 && cfg->device_ids)
+            full.gpu_id = cfg->device_ids[0];
+        full.num_devices = 0;
+        full.device_ids = nullptr;
+        return createOne(full, out);
+    }
+    // ---- one shard per listed device, each a renderer of its own over a contiguous world range
+    if (cfg->stream)
+        return fail(MRX_E_INVALID, "a renderer of several devices launches on each device's null stream: "
+                                   "mrx_config.stream must be null (mrx_set_stream on a shard sets its stream)");
+    mrx_renderer *top = new mrx_renderer();
+    top->mode = cfg->render_mode;
+    top->flags = cfg->flags;
+    top->variant = cfg->kernel_variant;
+    top->device = cfg->device_ids[0];
+    const uint32_t n = cfg->num_devices;
+    for (uint32_t i = 0; i < n; ++i) {
+        mrx_config sub = full;
+        const uint32_t lo = shardFirstWorld(cfg->num_worlds, i, n), hi = shardFirstWorld(cfg->num_worlds, i + 1, n);
+        sub.gpu_id = cfg->device_ids[i];
+        sub.worlds = cfg->worlds ? cfg->worlds + lo : nullptr;
+        sub.num_worlds = hi - lo;
+        sub.num_devices = 0;
+        sub.device_ids = nullptr;
+        mrx_renderer *sh = nullptr;
+        const int rc = createOne(sub, &sh);
+        if (rc != MRX_OK) {
+            const std::string why = g_err;
+            delete top;                               // (destroys the shards made so far)
+            return fail(rc, "shard " + std::to_string(i) + " (device " + std::to_string(sub.gpu_id) + "): " + why);
+        }
+        top->shards.push_back(sh);
+        top->shardFirstWorld.push_back(lo);
+    }
+    top->shardFirstWorld.push_back(cfg->num_worlds);
+    *out = top;
+    return MRX_OK;
+}
+
 void mrx_destroy(mrx_renderer *r)
 {
     if (!r)
         return;
-    (void)hipSetDevice(r->device);
-    (void)hipStreamSynchronize(r->stream);
+    for (mrx_renderer *sh : r->shards) {
+        (void)hipSetDevice(sh->device);
+        (void)hipStreamSynchronize(sh->stream);
+    }
+    if (r->shards.empty()) {
+        (void)hipSetDevice(r->device);
+        (void)hipStreamSynchronize(r->stream);
+    }
     delete r;
 }
 
@@ -1088,6 +1224,15 @@ int mrx_render(mrx_renderer *r)
 {
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
+    // several devices: one launch each, enqueued back to back from this thread -- device
+    // i + 1 is launched while device i renders; nothing here waits
+    for (mrx_renderer *sh : r->shards) {
+        const int rc = mrx_render(sh);
+        if (rc != MRX_OK)
+            return rc;
+    }
+    if (!r->shards.empty())
+        return MRX_OK;
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(r->launch());
     return MRX_OK;
@@ -1108,6 +1253,13 @@ int mrx_sync(mrx_renderer *r)
 {
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
+    for (mrx_renderer *sh : r->shards) {
+        const int rc = mrx_sync(sh);
+        if (rc != MRX_OK)
+            return rc;
+    }
+    if (!r->shards.empty())
+        return MRX_OK;
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(hipStreamSynchronize(r->stream));
     return MRX_OK;
@@ -1115,10 +1267,85 @@ int mrx_sync(mrx_renderer *r)
 
 void *mrx_stream(mrx_renderer *r) { return r ? (void *)r->stream : nullptr; }
 
+static int wantsShard(const char *what)
+{
+    return fail(MRX_E_UNSUPPORTED, std::string(what) + ": this renderer spans several devices -- "
+                                   "address one shard (mrx_shard / mrx_buffer_shard)");
+}
+
+int mrx_num_shards(mrx_renderer *r) { return !r ? 0 : r->shards.empty() ? 1 : (int)r->shards.size(); }
+
+mrx_renderer *mrx_shard(mrx_renderer *r, int shard)
+{
+    if (!r || shard < 0 || shard >= mrx_num_shards(r)) {
+        fail(MRX_E_INVALID, "no such shard");
+        return nullptr;
+    }
+    return r->shards.empty() ? r : r->shards[shard];
+}
+
+void *mrx_buffer_shard(mrx_renderer *r, int shard, int which, int64_t dims[4], int *ndim, int *dtype,
+                       int *device)
+{
+    mrx_renderer *sh = mrx_shard(r, shard);
+    return sh ? mrx_buffer(sh, which, dims, ndim, dtype, device) : nullptr;
+}
+
+int64_t mrx_shard_split(uint32_t num_worlds, uint32_t shard, uint32_t num_shards)
+{
+    if (num_shards == 0 || shard > num_shards)
+        return fail(MRX_E_INVALID, "bad shard");
+    return (int64_t)shardFirstWorld(num_worlds, shard, num_shards);
+}
+
+int64_t mrx_shard_first_world(mrx_renderer *r, int shard)
+{
+    if (!r || shard < 0 || shard > mrx_num_shards(r))
+        return fail(MRX_E_INVALID, "no such shard");
+    if (r->shards.empty())
+        return shard == 0 ? 0 : (int64_t)r->info.num_worlds;
+    return (int64_t)r->shardFirstWorld[shard];
+}
+
+int mrx_refresh_objects(mrx_renderer *r)
+{
+    if (!r)
+        return fail(MRX_E_INVALID, "null renderer");
+    for (mrx_renderer *sh : r->shards) {
+        const int rc = mrx_refresh_objects(sh);
+        if (rc != MRX_OK)
+            return rc;
+    }
+    if (!r->shards.empty())
+        return MRX_OK;
+    MRX_HIP(hipSetDevice(r->device));
+    // renders in flight read the tables that are about to change
+    MRX_HIP(hipStreamSynchronize(r->stream));
+    std::vector<int32_t> live(r->boundObj.size());
+    if (!live.empty())
+        MRX_HIP(hipMemcpy(live.data(), r->instObj.ptr, live.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    bool changed = false;
+    for (size_t i = 0; i < live.size(); ++i)
+        if (live[i] >= 0 && live[i] != r->boundObj[i]) {
+            r->boundObj[i] = live[i];
+            changed = true;
+        }
+    if (!changed)
+        return MRX_OK;
+    const bool wasBvh = r->useBvh;
+    const int rc = bindGeometry(*r);
+    if (rc != MRX_OK)
+        return rc;
+    (void)wasBvh;
+    return MRX_OK;
+}
+
 int mrx_set_stream(mrx_renderer *r, void *stream)
 {
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
+    if (!r->shards.empty())
+        return wantsShard("mrx_set_stream");
     MRX_HIP(hipSetDevice(r->device));
     if ((hipStream_t)stream == r->stream)
         return MRX_OK;
@@ -1134,6 +1361,10 @@ void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dt
 {
     if (!r || !dims || !ndim || !dtype) {
         fail(MRX_E_INVALID, "null argument");
+        return nullptr;
+    }
+    if (!r->shards.empty()) {
+        wantsShard("mrx_buffer");
         return nullptr;
     }
     const bool rt = r->mode == MRX_MODE_RAYTRACER;
@@ -1202,6 +1433,8 @@ int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes)
 {
     if (!r || !dst)
         return fail(MRX_E_INVALID, "null argument");
+    if (!r->shards.empty())
+        return wantsShard("mrx_copy_to_host");
     int64_t dims[4] = { 1, 1, 1, 1 };
     int nd = 0, dt = 0, dev = 0;
     void *src = mrx_buffer(r, which, dims, &nd, &dt, &dev);
@@ -1222,6 +1455,23 @@ int mrx_info(mrx_renderer *r, mrx_info_t *out)
 {
     if (!r || !out)
         return fail(MRX_E_INVALID, "null argument");
+    if (!r->shards.empty()) {
+        // the shards share the scene: counts of what is per world add up, the rest is shard 0's
+        mrx_info_t sum = r->shards[0]->info;
+        for (size_t i = 1; i < r->shards.size(); ++i) {
+            const mrx_info_t &o = r->shards[i]->info;
+            sum.num_worlds += o.num_worlds;
+            sum.num_views += o.num_views;
+            sum.num_instances += o.num_instances;
+            sum.bytes_per_step += o.bytes_per_step;
+            sum.max_world_triangles = std::max(sum.max_world_triangles, o.max_world_triangles);
+            sum.max_world_instances = std::max(sum.max_world_instances, o.max_world_instances);
+            sum.render_path = std::max(sum.render_path, o.render_path);
+        }
+        sum.num_shards = (uint32_t)r->shards.size();
+        *out = sum;
+        return MRX_OK;
+    }
     *out = r->info;
     return MRX_OK;
 }
@@ -1230,6 +1480,32 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
 {
     if (!r || !ms_total || steps < 0)
         return fail(MRX_E_INVALID, "bad argument");
+    if (!r->shards.empty()) {
+        // every device runs its `steps` launches between its own two events, all enqueued
+        // before anything is waited for: the job takes as long as the slowest device
+        for (mrx_renderer *sh : r->shards) {
+            MRX_HIP(hipSetDevice(sh->device));
+            MRX_HIP(hipEventRecord(sh->ev0, sh->stream));
+        }
+        for (int i = 0; i < steps; ++i)
+            for (mrx_renderer *sh : r->shards) {
+                MRX_HIP(hipSetDevice(sh->device));
+                MRX_HIP(sh->launch());
+            }
+        *ms_total = 0.0f;
+        for (mrx_renderer *sh : r->shards) {
+            MRX_HIP(hipSetDevice(sh->device));
+            MRX_HIP(hipEventRecord(sh->ev1, sh->stream));
+        }
+        for (mrx_renderer *sh : r->shards) {
+            float ms = 0.0f;
+            MRX_HIP(hipSetDevice(sh->device));
+            MRX_HIP(hipEventSynchronize(sh->ev1));
+            MRX_HIP(hipEventElapsedTime(&ms, sh->ev0, sh->ev1));
+            *ms_total = std::max(*ms_total, ms);
+        }
+        return MRX_OK;
+    }
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(hipEventRecord(r->ev0, r->stream));
     for (int i = 0; i < steps; ++i)
@@ -1242,6 +1518,8 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
 
 int64_t mrx_debug_stamps(mrx_renderer *r, uint64_t *dst, int64_t capacity)
 {
+    if (r && !r->shards.empty())
+        r = r->shards[0];
     if (!r || !dst || !r->stamps.ptr)
         return 0;
     const int64_t n = (int64_t)r->stamps.count < capacity ? (int64_t)r->stamps.count : capacity;
@@ -1255,6 +1533,13 @@ int mrx_mark(mrx_renderer *r, int which)
 {
     if (!r || (which != 0 && which != 1))
         return fail(MRX_E_INVALID, "bad argument");
+    for (mrx_renderer *sh : r->shards) {
+        const int rc = mrx_mark(sh, which);
+        if (rc != MRX_OK)
+            return rc;
+    }
+    if (!r->shards.empty())
+        return MRX_OK;
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(hipEventRecord(which ? r->ev1 : r->ev0, r->stream));
     return MRX_OK;
@@ -1264,6 +1549,17 @@ int mrx_elapsed_ms(mrx_renderer *r, float *ms)
 {
     if (!r || !ms)
         return fail(MRX_E_INVALID, "null argument");
+    if (!r->shards.empty()) {                     // the slowest device
+        *ms = 0.0f;
+        for (mrx_renderer *sh : r->shards) {
+            float one = 0.0f;
+            const int rc = mrx_elapsed_ms(sh, &one);
+            if (rc != MRX_OK)
+                return rc;
+            *ms = std::max(*ms, one);
+        }
+        return MRX_OK;
+    }
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(hipEventSynchronize(r->ev1));
     MRX_HIP(hipEventElapsedTime(ms, r->ev0, r->ev1));
@@ -1272,6 +1568,8 @@ int mrx_elapsed_ms(mrx_renderer *r, float *ms)
 
 int mrx_placement(mrx_renderer *r, float *cand_us, int capacity, float *kept_us)
 {
+    if (r && !r->shards.empty())
+        r = r->shards[0];
     if (!r || (!cand_us && capacity > 0))
         return fail(MRX_E_INVALID, "bad argument");
     for (size_t i = 0; i < r->placementUs.size() && (int)i < capacity; ++i)
@@ -1284,6 +1582,8 @@ int mrx_placement(mrx_renderer *r, float *cand_us, int capacity, float *kept_us)
 int mrx_copy_triangles(mrx_renderer *r, float *tri_pos, float *tri_uv, int32_t *tri_mat,
                        int32_t *obj_first, int32_t *obj_count)
 {
+    if (r && !r->shards.empty())
+        r = r->shards[0];                         // every shard holds the whole object pool
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
     for (size_t t = 0; t < r->hostTris.size(); ++t) {

@@ -114,6 +114,23 @@ using FArr = py::array_t<T, py::array::c_style | py::array::forcecast>;
 
 PyTensor wrapTensor(py::object self, Tensor t) { return PyTensor { t, std::move(self) }; }
 
+// `shard` of the tensor getters: None means "the renderer's one shard" -- an error when the
+// renderer spans several devices (each shard's tensors live on its own device)
+uint32_t shardOf(const py::object &self, const py::object &shard)
+{
+    const uint32_t n = self.cast<Manager &>().numShards();
+    if (shard.is_none()) {
+        if (n > 1)
+            throw py::value_error("this renderer spans " + std::to_string(n) +
+                                  " devices: say which shard's tensor (shard=i)");
+        return 0;
+    }
+    const long i = shard.cast<long>();
+    if (i < 0 || (unsigned long)i >= n)
+        throw py::index_error("shard " + std::to_string(i) + " of " + std::to_string(n));
+    return (uint32_t)i;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(madrona_renderer, m)
@@ -221,7 +238,8 @@ PYBIND11_MODULE(madrona_renderer, m)
                          const std::vector<std::string> &texture_paths,
                          const std::vector<ImportedInstance> &instances,
                          const std::vector<ImportedCamera> &cameras,
-                         const std::vector<Sim::WorldInit> &worlds) {
+                         const std::vector<Sim::WorldInit> &worlds,
+                         const std::vector<int> &device_ids, int max_instances_per_world) {
                  if (mesh_vertices.size() && (mesh_vertices.ndim() != 2 || mesh_vertices.shape(1) != 3))
                      throw py::value_error("mesh_vertices must have shape [N, 3]");
                  if (mesh_uvs.size() && (mesh_uvs.ndim() != 2 || mesh_uvs.shape(1) != 2))
@@ -276,6 +294,12 @@ PYBIND11_MODULE(madrona_renderer, m)
                  cfg.rcfg.cameras = const_cast<ImportedCamera *>(cameras.data());
                  cfg.rcfg.numCameras = (uint32_t)cameras.size();
                  cfg.rcfg.worlds = const_cast<Sim::WorldInit *>(worlds.data());
+                 // additions: one renderer over several devices; spare instance rows
+                 cfg.deviceIDs = device_ids.empty() ? nullptr : device_ids.data();
+                 cfg.numDevices = (uint32_t)device_ids.size();
+                 if (max_instances_per_world < 0)
+                     throw py::value_error("max_instances_per_world must not be negative");
+                 cfg.maxInstancesPerWorld = (uint32_t)max_instances_per_world;
                  return new Manager(cfg);
              }),
              py::arg("gpu_id"), py::arg("num_worlds"), py::arg("render_mode"),
@@ -284,41 +308,66 @@ PYBIND11_MODULE(madrona_renderer, m)
              py::arg("mesh_indices"), py::arg("mesh_vertex_offsets"),
              py::arg("mesh_indices_offsets"), py::arg("mesh_materials"), py::arg("materials"),
              py::arg("texture_paths"), py::arg("instances"), py::arg("cameras"),
-             py::arg("worlds"))
+             py::arg("worlds"),
+             // not in the reference (its callers never pass them): device_ids = [d0, d1, ...] makes this
+             // one renderer span several devices (gpu_id is then ignored), max_instances_per_world
+             // reserves hidden, unbound rows per world (see refresh_objects)
+             py::arg("device_ids") = std::vector<int>(), py::arg("max_instances_per_world") = 0)
         .def("step", &Manager::step)
         .def("render", &Manager::render)
         .def("sync", &Manager::sync)
         .def("rgb_tensor",
-             [](py::object self) { return wrapTensor(self, self.cast<Manager &>().rgbTensor()); })
+             [](py::object self, py::object shard) { return wrapTensor(self, self.cast<Manager &>().rgbTensor(shardOf(self, shard))); },
+             py::arg("shard") = py::none())
         .def("depth_tensor",
-             [](py::object self) { return wrapTensor(self, self.cast<Manager &>().depthTensor()); })
+             [](py::object self, py::object shard) { return wrapTensor(self, self.cast<Manager &>().depthTensor(shardOf(self, shard))); },
+             py::arg("shard") = py::none())
         .def("segmask_tensor",
-             [](py::object self) { return wrapTensor(self, self.cast<Manager &>().segmaskTensor()); })
+             [](py::object self, py::object shard) { return wrapTensor(self, self.cast<Manager &>().segmaskTensor(shardOf(self, shard))); },
+             py::arg("shard") = py::none())
         .def("visibility_tensor",
-             [](py::object self) { return wrapTensor(self, self.cast<Manager &>().visibilityTensor()); })
-        .def("rgb_cuda_ptr", &Manager::rgbCudaPtr)
-        .def("depth_cuda_ptr", &Manager::depthCudaPtr)
-        .def("segmask_cuda_ptr", &Manager::segmaskCudaPtr)
+             [](py::object self, py::object shard) { return wrapTensor(self, self.cast<Manager &>().visibilityTensor(shardOf(self, shard))); },
+             py::arg("shard") = py::none())
+        .def("rgb_cuda_ptr", [](py::object self, py::object shard) { return self.cast<Manager &>().rgbCudaPtr(shardOf(self, shard)); },
+             py::arg("shard") = py::none())
+        .def("depth_cuda_ptr", [](py::object self, py::object shard) { return self.cast<Manager &>().depthCudaPtr(shardOf(self, shard)); },
+             py::arg("shard") = py::none())
+        .def("segmask_cuda_ptr", [](py::object self, py::object shard) { return self.cast<Manager &>().segmaskCudaPtr(shardOf(self, shard)); },
+             py::arg("shard") = py::none())
+        .def("instance_scale_tensor",
+             [](py::object self, py::object shard) {
+                 return wrapTensor(self, self.cast<Manager &>().instanceScaleTensor(shardOf(self, shard)));
+             },
+             py::arg("shard") = py::none())
+        // binds rows to the object ids their ObjectID column holds (spare rows: max_instances_per_world)
+        .def("refresh_objects", &Manager::refreshObjects)
+        .def_property_readonly("num_shards", &Manager::numShards)
+        .def("shard_first_world", &Manager::shardFirstWorld, py::arg("shard"))
         .def("instance_position_tensor",
-             [](py::object self) {
-                 return wrapTensor(self, self.cast<Manager &>().instancePositionTensor());
-             })
+             [](py::object self, py::object shard) {
+                 return wrapTensor(self, self.cast<Manager &>().instancePositionTensor(shardOf(self, shard)));
+             },
+             py::arg("shard") = py::none())
         .def("instance_object_tensor",
-             [](py::object self) {
-                 return wrapTensor(self, self.cast<Manager &>().instanceObjectTensor());
-             })
+             [](py::object self, py::object shard) {
+                 return wrapTensor(self, self.cast<Manager &>().instanceObjectTensor(shardOf(self, shard)));
+             },
+             py::arg("shard") = py::none())
         .def("instance_rotation_tensor",
-             [](py::object self) {
-                 return wrapTensor(self, self.cast<Manager &>().instanceRotationTensor());
-             })
+             [](py::object self, py::object shard) {
+                 return wrapTensor(self, self.cast<Manager &>().instanceRotationTensor(shardOf(self, shard)));
+             },
+             py::arg("shard") = py::none())
         .def("camera_position_tensor",
-             [](py::object self) {
-                 return wrapTensor(self, self.cast<Manager &>().cameraPositionTensor());
-             })
+             [](py::object self, py::object shard) {
+                 return wrapTensor(self, self.cast<Manager &>().cameraPositionTensor(shardOf(self, shard)));
+             },
+             py::arg("shard") = py::none())
         .def("camera_rotation_tensor",
-             [](py::object self) {
-                 return wrapTensor(self, self.cast<Manager &>().cameraRotationTensor());
-             })
+             [](py::object self, py::object shard) {
+                 return wrapTensor(self, self.cast<Manager &>().cameraRotationTensor(shardOf(self, shard)));
+             },
+             py::arg("shard") = py::none())
         .def("time_renders", &Manager::timeRenders, py::arg("steps"))
         .def("mark", &Manager::mark, py::arg("which"))
         .def("elapsed_ms", &Manager::elapsedMs)

@@ -38,6 +38,8 @@ class SceneDesc:
     instances: list = field(default_factory=list)       # [(pos, rot, scale, obj)]
     cameras: list = field(default_factory=list)         # [(pos, rot)]
     worlds: list = field(default_factory=list)          # [(ni, io, nc, co)]
+    # rows per world at least (spare rows start hidden and unbound: refresh_objects)
+    max_instances_per_world: int = 0
 
     def __post_init__(self):
         if self.mesh_vertices is None:
@@ -225,11 +227,18 @@ def demo_scene(num_worlds=4, render_mode="Raytracer", width=64, height=64,
         worlds=[(2, 0, 1, 0)] * num_worlds)
 
 
-def make_renderer(desc, gpu_id=0):
+def make_renderer(desc, gpu_id=0, device_ids=None):
     """Instantiate the product renderer (compiled ``madrona_renderer`` module,
-    HIP only) from a SceneDesc, with the reference's constructor kwargs."""
+    HIP only) from a SceneDesc, with the reference's constructor kwargs.
+    ``device_ids`` = [d0, d1, ...] makes the one renderer span several devices
+    (contiguous world ranges, one shard per listed device)."""
     from . import load_module
     m = load_module()
+    extra = {}
+    if device_ids is not None:
+        extra["device_ids"] = [int(d) for d in device_ids]
+    if desc.max_instances_per_world:
+        extra["max_instances_per_world"] = int(desc.max_instances_per_world)
     return m.MadronaRenderer(
         gpu_id=gpu_id,
         num_worlds=desc.num_worlds,
@@ -253,4 +262,5 @@ def make_renderer(desc, gpu_id=0):
         cameras=[m.ImportedCamera(position=list(p), rotation=list(q))
                  for p, q in desc.cameras],
         worlds=[m.WorldInit(num_instances=a, instance_offset=b, num_cameras=c,
-                            camera_offset=d) for a, b, c, d in desc.worlds])
+                            camera_offset=d) for a, b, c, d in desc.worlds],
+        **extra)

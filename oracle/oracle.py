@@ -262,8 +262,9 @@ def decode_bc7(blocks, width, height):
 
 
 def decode_ktx2(path):
-    """KTX 2.0 (BC7 or RGBA8 base level, supercompression none / ZLIB) -> RGBA8.
-    An independent reading of the container (struct) and of BC7 (Pillow)."""
+    """KTX 2.0 (BC7 or RGBA8 base level, supercompression none / Zstandard / ZLIB) ->
+    RGBA8.  An independent reading of the container (struct), of BC7 (Pillow) and of
+    Zstandard (pyarrow's codec)."""
     import struct
     import zlib
     with open(path, "rb") as f:
@@ -272,11 +273,14 @@ def decode_ktx2(path):
         raise OSError("not a KTX2 file")
     vk, _ts, w, h, d, layers, faces, levels, scheme = struct.unpack_from("<9I", data, 12)
     off, length, _ulen = struct.unpack_from("<3Q", data, 80)
-    if d > 1 or layers > 1 or faces != 1 or vk not in (37, 43, 145, 146) or scheme not in (0, 3):
+    if d > 1 or layers > 1 or faces != 1 or vk not in (37, 43, 145, 146) or scheme not in (0, 2, 3):
         raise OSError("unsupported KTX2")
     payload = data[off:off + length]
     if scheme == 3:
         payload = zlib.decompress(payload)
+    elif scheme == 2:
+        import pyarrow
+        payload = pyarrow.decompress(payload, decompressed_size=int(_ulen), codec="zstd").to_pybytes()
     if vk in (37, 43):
         return np.frombuffer(payload[:w * h * 4], np.uint8).reshape(h, w, 4).copy()
     return decode_bc7(payload[:((w + 3) // 4) * ((h + 3) // 4) * 16], w, h)
@@ -453,10 +457,18 @@ class FlatScene:
         cams = list(desc.cameras)
         ipos, irot, iscl, iobj, wstart = [], [], [], [], [0]
         cpos, crot, vworld = [], [], []
+        # max_instances_per_world: a world owns that many rows at least; the spare ones
+        # start hidden and unbound (ObjectID -1, identity pose) -- the reference sizes its
+        # renderer by maxInstancesPerWorld (/root/reference/src/mgr.cpp:378-388) and creates
+        # renderables at run time (src/sim.inl:5-8)
+        cap = int(getattr(desc, "max_instances_per_world", 0) or 0)
         for w, (ni, io, nc, co) in enumerate(desc.worlds):
             for r in inst[io:io + ni]:
                 ipos.append(r[0]); irot.append(r[1]); iscl.append(r[2])
                 iobj.append(r[3])
+            for _ in range(max(0, cap - ni)):
+                ipos.append((0.0, 0.0, 0.0)); irot.append((1.0, 0.0, 0.0, 0.0)); iscl.append((1.0, 1.0, 1.0))
+                iobj.append(-1)
             wstart.append(len(ipos))
             for r in cams[co:co + nc]:
                 cpos.append(r[0]); crot.append(r[1]); vworld.append(w)
@@ -464,14 +476,21 @@ class FlatScene:
         self.inst_rot = np.asarray(irot, dtype=np.float32).reshape(-1, 4)
         self.inst_scale = np.asarray(iscl, dtype=np.float32).reshape(-1, 3)
         self.inst_obj = np.asarray(iobj, dtype=np.int32)
-        # ObjectID at creation binds geometry and triangle slots; tests hide an
-        # instance by writing a negative id into inst_obj afterwards
+        # inst_obj0 = the object each row is BOUND to (geometry, triangle slots, segmask
+        # label); inst_obj = the live ObjectID column, of which only the sign is read
+        # (negative hides).  refresh_objects() re-binds, as mrx_refresh_objects does.
         self.inst_obj0 = self.inst_obj.copy()
         self.world_inst_start = np.asarray(wstart, dtype=np.int32)
         self.cam_pos = np.asarray(cpos, dtype=np.float32).reshape(-1, 3)
         self.cam_rot = np.asarray(crot, dtype=np.float32).reshape(-1, 4)
         self.view_world = np.asarray(vworld, dtype=np.int32)
         self.num_views = len(vworld)
+
+    def refresh_objects(self):
+        """Bind every row whose live id is non-negative to that object (rows holding a
+        negative id stay bound to what they drew): include/mrx.h, mrx_refresh_objects."""
+        live = self.inst_obj >= 0
+        self.inst_obj0[live] = self.inst_obj[live]
 
     def _struct(self):
         s = _Scene()

@@ -4,6 +4,9 @@ its "ktx2" handler is /root/reference/src/mgr.cpp:199-212,297-298):
   cube64_bc7.ktx2      data/cube.png reduced to 64x64, BC7 (mode 6 blocks), vkFormat 145
   bc7_modes.ktx2       32x32, 64 blocks with random payloads, eight of every BC7 mode
   bc7_modes_zlib.ktx2  the same level, supercompression scheme 3 (ZLIB), vkFormat 146
+  bc7_modes_zstd.ktx2  the same level, supercompression scheme 2 (Zstandard, written with
+                       pyarrow's codec)
+  rgba8_zstd_9x7.ktx2  a 9x7 R8G8B8A8_UNORM image, Zstandard
   rgba8_5x3.ktx2       a 5x3 R8G8B8A8_UNORM image (no block compression, ragged size)
   ktx2_expected.npz    what they decode to, by Pillow's BC7 decoder (independent of
                        madrona_renderer_amd/csrc/ktx2.cpp)
@@ -114,6 +117,17 @@ def main():
     files["bc7_modes.ktx2"] = ktx2(145, 32, 32, blocks)
     files["bc7_modes_zlib.ktx2"] = ktx2(146, 32, 32, zlib.compress(blocks, 9), scheme=3,
                                         uncompressed_len=len(blocks))
+    import pyarrow
+    files["bc7_modes_zstd.ktx2"] = ktx2(145, 32, 32, pyarrow.compress(blocks, codec="zstd", asbytes=True), scheme=2,
+                                        uncompressed_len=len(blocks))
+    # (a compressible image, so the frame holds matches and not only literals)
+    grad = np.zeros((7, 9, 4), np.uint8)
+    grad[..., 0] = np.arange(9)[None, :] * 28
+    grad[..., 1] = np.arange(7)[:, None] * 36
+    grad[..., 2] = 77
+    grad[..., 3] = 255
+    files["rgba8_zstd_9x7.ktx2"] = ktx2(37, 9, 7, pyarrow.compress(grad.tobytes(), codec="zstd", asbytes=True),
+                                        scheme=2, uncompressed_len=grad.size)
     small = rng.integers(0, 256, size=(3, 5, 4), dtype=np.uint8)
     files["rgba8_5x3.ktx2"] = ktx2(37, 5, 3, small.tobytes())
     expected = {}
@@ -123,6 +137,8 @@ def main():
             f.write(data)
         expected[name] = oracle.decode_image(path)
     assert np.array_equal(expected["bc7_modes.ktx2"], expected["bc7_modes_zlib.ktx2"])
+    assert np.array_equal(expected["bc7_modes.ktx2"], expected["bc7_modes_zstd.ktx2"])
+    assert np.array_equal(expected["rgba8_zstd_9x7.ktx2"], grad)
     assert np.array_equal(expected["rgba8_5x3.ktx2"], small)
     err = np.abs(expected["cube64_bc7.ktx2"].astype(int) - cube.astype(int))
     print("mode-6 encoder: mean abs error %.2f, max %d" % (err.mean(), err.max()))

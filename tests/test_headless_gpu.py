@@ -64,7 +64,7 @@ def test_synthetic_scene_matches_python_generator(native, tmp_path):
 
 
 def test_sharded_over_devices_renders_the_same_worlds(native, tmp_path, monkeypatch):
-    # --gpus N: one host thread + Manager per device, contiguous world shards.
+    # --gpus N: ONE Manager over N devices (Config::deviceIDs), contiguous world shards.
     # On this one-GPU box the rehearsal switch puts every shard on device 0; the
     # per-shard dumps must tile exactly the worlds a single renderer draws.
     r = _run([10, 2, "rast", 64, 64, "--gpus", "3"], tmp_path)

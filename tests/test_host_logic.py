@@ -25,7 +25,7 @@ def test_capi_exports_every_declared_symbol(native):
     for n in names:
         assert hasattr(lib, n), f"libmrx_hip.so does not export {n}"
     lib.mrx_abi_version.restype = ctypes.c_int
-    assert lib.mrx_abi_version() == 2
+    assert lib.mrx_abi_version() == 3
 
 
 def test_module_surface_matches_reference_bindings(native):
@@ -300,3 +300,46 @@ def test_obj_file_is_one_object_and_blocks_split_on_request(native, oracle_mod, 
     monkeypatch.setenv("MRX_OBJ_SPLIT_BLOCKS", "1")
     fs = oracle_mod.FlatScene(d)
     assert fs.obj_first_tri.tolist() == [0, 2, 5, 7, 9] and fs.obj_num_tris.tolist() == [2, 3, 2, 2, 1]
+
+
+def test_library_shard_split_is_scenes_shard_range(native):
+    # single-process multi-device (mrx_config.device_ids): the library splits the worlds exactly
+    # as the one-process-per-GPU path does (scenes.shard_range), so shard i of a multi-device
+    # renderer holds the worlds rank i of a torchrun job would
+    lib = native.load_capi()
+    lib.mrx_shard_split.restype = ctypes.c_int64
+    lib.mrx_shard_split.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    for n in (0, 1, 7, 8, 9, 4096, 16384, 1000003):
+        for k in (1, 2, 3, 4, 8, 64):
+            for i in range(k):
+                lo, hi = scenes.shard_range(n, i, k)
+                assert lib.mrx_shard_split(n, i, k) == lo and lib.mrx_shard_split(n, i + 1, k) == hi
+    assert lib.mrx_shard_split(10, 5, 4) < 0 and lib.mrx_shard_split(10, 0, 0) < 0
+
+
+def test_oracle_spare_rows_and_rebinding(oracle_mod):
+    # max_instances_per_world: spare rows start hidden and unbound; refresh_objects binds a row to
+    # the id its ObjectID column holds, and the world-local triangle numbering follows row order
+    d = scenes.synthetic_scene(3)
+    d.max_instances_per_world = 4
+    fs = oracle_mod.FlatScene(d)
+    assert fs.world_inst_start.tolist() == [0, 4, 8, 12]
+    assert fs.inst_obj.tolist() == [1, 0, -1, -1] * 3 and np.array_equal(fs.inst_obj, fs.inst_obj0)
+    plain = oracle_mod.FlatScene(scenes.synthetic_scene(3)).render()
+    before = fs.render()
+    for k in ("rgb", "depth", "tri_id", "segmask"):
+        assert np.array_equal(plain[k], before[k]), k             # unbound rows draw nothing
+    # spawn a second cube in world 1 (row 6): id written, then bound
+    fs.inst_obj[6] = 0
+    fs.inst_pos[6] = (1.5, -2.0, 2.0)
+    same = fs.render()
+    assert np.array_equal(same["tri_id"], before["tri_id"])        # not bound yet: only the sign counts
+    fs.refresh_objects()
+    after = fs.render()
+    assert not np.array_equal(after["tri_id"][1], before["tri_id"][1])
+    assert np.array_equal(after["tri_id"][0], before["tri_id"][0]) and np.array_equal(after["tri_id"][2], before["tri_id"][2])
+    assert after["tri_id"][1].max() >= 14                          # its triangles are numbered after the cube's and plane's
+    # a different non-negative id without refresh changes neither geometry nor labels
+    fs.inst_obj[0] = 0
+    again = fs.render()
+    assert np.array_equal(again["segmask"], after["segmask"]) and np.array_equal(again["rgb"], after["rgb"])

@@ -93,9 +93,18 @@ def test_ktx2_reader_refuses_what_it_cannot_read(native, tmp_path):
     rc, msg = attempt(bytes(etc))
     assert rc != 0 and "vkFormat 147" in msg
     zstd = bytearray(good)
-    struct.pack_into("<I", zstd, 44, 2)
+    struct.pack_into("<I", zstd, 44, 2)                            # says Zstandard, holds raw blocks
     rc, msg = attempt(bytes(zstd))
+    assert rc != 0 and "Zstandard payload does not decompress" in msg
+    lzma = bytearray(good)
+    struct.pack_into("<I", lzma, 44, 4)                            # no such scheme
+    rc, msg = attempt(bytes(lzma))
     assert rc != 0 and "supercompression" in msg
+    real = bytearray(open(os.path.join(GOLDEN, "bc7_modes_zstd.ktx2"), "rb").read())
+    assert attempt(bytes(real))[0] == 0
+    off = struct.unpack_from("<Q", real, 80)[0]
+    real[off] ^= 0xFF                                              # not a Zstandard frame any more (magic number)
+    assert attempt(bytes(real))[0] != 0
     cube = bytearray(good)
     struct.pack_into("<I", cube, 36, 6)                            # six faces
     assert attempt(bytes(cube))[0] != 0
