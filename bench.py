@@ -224,22 +224,25 @@ def settle(r, seconds):
     return n
 
 
-def bvh_roofline(r, kern_us, views, tiles_per_view):
+def bvh_roofline(tag, kern_us, views, tiles_per_view):
     """The BVH kernel is not HBM-bound: its own roofline is the VALU
-    issue rate.  Instruction counts per wave come from the committed SQ-counter summary
-    of the 482-triangle shape (profiles/pmc_latest.json, key "bvh_sq"); the peak is one
-    VALU instruction per cycle per SIMD (MI355X_MICROARCH.md: 4 SIMDs x 256 CUs at
-    2.4 GHz), i.e. 2457.6 G wave-instructions/s."""
-    ent = pmc_table().get("bvh_sq")
-    if not isinstance(ent, dict):
+    issue rate.  VALU instructions per wave come from the committed SQ-counter summary
+    of exactly this workload (profiles/pmc_latest.json, "sq" of the workload's entry;
+    SQ_INSTS_VALU / SQ_WAVES); the peak is what 1024 SIMDs (256 CUs x 4) issue when
+    a wave64 vector instruction occupies its SIMD for four cycles at 2.4 GHz
+    (MI355X_MICROARCH.md; measured here: v_fma_f32 4.3 cycles per wave and SIMD):
+    614.4 G wave-instructions/s."""
+    ent = pmc_table().get(tag)
+    sq = ent.get("sq") if isinstance(ent, dict) else None
+    if not isinstance(sq, dict) or not sq.get("valu_per_wave"):
         return None
     waves = views * tiles_per_view * 8
-    valu = float(ent.get("valu_per_wave", 0.0)) * waves
-    peak = 256 * 4 * 2.4e9
+    valu = float(sq["valu_per_wave"]) * waves
+    peak = 256 * 4 * 2.4e9 / 4.0
     achieved = valu / (kern_us * 1e-6)
     return {"bound": "valu-issue", "achieved": achieved / 1e9, "peak": peak / 1e9,
             "unit": "G wave-instr/s", "frac": achieved / peak,
-            "valu_per_wave": ent.get("valu_per_wave"), "source": ent.get("source")}
+            "valu_per_wave": sq["valu_per_wave"], "sq_source": sq.get("source")}
 
 
 def run_dry(a):
@@ -422,7 +425,7 @@ def run_rank(a):
     }
     if r.render_path() == "bvh":
         tiles = ((a.width + 63) // 64) * ((a.height + 63) // 64)
-        own = bvh_roofline(r, kern_us, views, tiles)
+        own = bvh_roofline(workload_tag(a, n_gpus), kern_us, views, tiles)
         if own is not None:
             # the HBM figures stay, as frac_hbm; `frac` is against the bound that applies
             hb = out["roofline"]

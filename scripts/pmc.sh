@@ -9,7 +9,7 @@ cd /tmp
 i=0
 for ctrs in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/pass$i" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra ${BENCH_ARGS:-} > "$OUT/pass$i.log" 2>&1 || tail -5 "$OUT/pass$i.log"
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/pass$i" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-strong ${BENCH_ARGS:-} > "$OUT/pass$i.log" 2>&1 || tail -5 "$OUT/pass$i.log"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

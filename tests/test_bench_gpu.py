@@ -126,3 +126,18 @@ def test_bench_line_on_the_bvh_path(native):
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert "bvh" in out["roofline"]["kernel"] and out["roofline"]["bytes_per_launch"] == 128 * (64 * 64 * 8 + 41 * 44 + 28)
     assert out["roofline"]["frac_wall"] <= out["roofline"]["frac_kernel"] * 1.05
+
+
+@pytest.mark.gpu
+def test_bvh_workload_with_committed_sq_counters_reports_its_own_roofline(native):
+    # the BVH kernel is issue-bound, not HBM-bound -- for the workload whose SQ counters
+    # are committed (profiles/pmc_latest.json, "sq" of 1024x64x64+cubes40) the line's roofline is the VALU issue
+    # rate, with the HBM fraction kept beside it
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "10",
+                        "--worlds", "1024", "--cubes", "40", "--no-cpu-baseline", "--no-extra", "--no-strong"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+    assert r["bound"] == "valu-issue" and r["unit"] == "G wave-instr/s" and abs(r["peak"] - 614.4) < 1e-6
+    assert 0.2 < r["frac"] < 1.0 and 0.05 < r["frac_hbm"] < 0.5 and r["valu_per_wave"] > 500
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "bvh" in r["kernel"]
