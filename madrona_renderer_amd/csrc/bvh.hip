@@ -251,11 +251,11 @@ __device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long 
                                              uint32_t tileY0, int wave, int lane)
 {
     constexpr int kHalves = TW / 32;
-    if (!FINAL) {
-        // This instantiation sits inside the round loop, and everything it computes is
-        // loop-invariant: left alone the compiler hoists the pixel addresses of both halves
-        // out of the loop and carries them through the traversal in registers it does not have.
-        // Laundering the two values they all derive from keeps the arithmetic in here.
+    {
+        // Both instantiations sit inside the kernel's loops (rounds, tiles of the group), and most
+        // of what they compute is loop-invariant: left alone the compiler hoists the pixel addresses
+        // of both halves out of the loops and carries them through the traversal in registers it does
+        // not have.  Laundering the two values they all derive from keeps the arithmetic in here.
         asm volatile("" : "+v"(lane));
         asm volatile("" : "+s"(view));
     }
@@ -430,11 +430,18 @@ void bvhTileKernel(const RasterParams p)
     // texels from HBM for itself.  When the grid divides by eight, XCD x takes the x-th eighth of
     // the items instead: the tiles of a view follow each other on one XCD.
     uint32_t item = blockIdx.x;
-    if (tilesPerView > 1 && (gridDim.x & 7u) == 0)
+    if ((tilesPerView > 1 || p.bvhGroupTiles > 1) && (gridDim.x & 7u) == 0)
         item = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t view = item / tilesPerView;
-    const uint32_t tile = item - view * tilesPerView;
-    const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
+    // A workgroup renders p.bvhGroupTiles consecutive tiles of one view, one after the other,
+    // over ONE build of the world's TLAS (worlds that fit a single TLAS pass; the launcher gives
+    // one tile per workgroup otherwise): the instance transforms, their screen rectangles and
+    // the view constants are per view, not per tile.
+    const uint32_t groupTiles = p.bvhGroupTiles;
+    const uint32_t groupsPerView = (tilesPerView + groupTiles - 1) / groupTiles;
+    const uint32_t view = item / groupsPerView;
+    uint32_t tile = (item - view * groupsPerView) * groupTiles;
+    const uint32_t lastTile = min(tile + groupTiles, tilesPerView);
+    uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
     const uint32_t passInst = p.bvhPassInst;
     const uint32_t dskip = MRX_BVH_DIAG ? p.debugSkip : 0u;
     if (dskip & 16u)
@@ -485,8 +492,8 @@ void bvhTileKernel(const RasterParams p)
     }
     const float isx = __builtin_amdgcn_rcpf(p.sx), isz = __builtin_amdgcn_rcpf(p.sz);
     const float invNear = p.invNear, invFar = p.invFar;
-    const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
-    const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
+    float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
+    float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
     const int smallArea = p.bvhSmallArea;
 
     {
@@ -504,8 +511,10 @@ void bvhTileKernel(const RasterParams p)
         }
     }
     if (threadIdx.x == 0)
-        ctrl[0] = ctrl[1] = ctrl[2] = ctrl[4] = ctrl[6] = 0u;   // records / done waves / large triangles;
-                                                                  // [4], [6]: records / large triangles of odd rounds
+        ctrl[0] = ctrl[1] = ctrl[2] = ctrl[3] = ctrl[4] = ctrl[6] = 0u;   // records / done waves / large triangles;
+                                                      // [4], [6]: records / large triangles of odd rounds;
+                                                      // [3]: done waves of the group's odd tiles
+    uint32_t doneIdx = 1;
 
     // the lane's pixels in the large pass and at resolve / output time: strip = wave, four
     // consecutive pixels of one row in each 32-pixel half
@@ -514,14 +523,16 @@ void bvhTileKernel(const RasterParams p)
     // the record and large-triangle counters alternate between two sets from
     // round to round, so the idle set can be prepared while the other is read
     uint32_t par = 0;
-    for (uint32_t passBase = i0; passBase < i1; passBase += passInst) {
-        const uint32_t n = min(passInst, i1 - passBase);
+    uint32_t passBase = i0;
+    do {                                              // (an empty world: one pass over no instances)
+        const uint32_t n = i1 > passBase ? min(passInst, i1 - passBase) : 0u;
+        const bool lastPass = passBase + passInst >= i1;
         if (passBase != i0) {
             // (the first pass has nothing to wait for: the barrier that closes phase I also
             // orders the clearing of the depth buffer above ahead of its first use)
             __syncthreads();                          // previous TLAS consumed
             if (threadIdx.x == 0)
-                ctrl[1] = 0u;     // done waves (every wave has read the last pass's count by now); the record and
+                ctrl[doneIdx] = 0u;  // done waves (every wave has read the last pass's count by now); the record and
                                   // large-triangle counters of the coming round were set at the end of the last one
         }
         // ---- phase I: the TLAS of this pass, in LDS.  Lane = instance: its transform
@@ -574,6 +585,7 @@ void bvhTileKernel(const RasterParams p)
         __syncthreads();
         MRX_STAMP(1);
 
+        for (;;) {                                    // the tiles of the group (one, unless the world fits one pass)
         // ---- phase II: geometry.  The waves split the work by instance: flat
         //      objects round-robin, the eight children of a BLAS root one per
         //      wave.  All control flow of a wave is wave-uniform.
@@ -919,7 +931,7 @@ void bvhTileKernel(const RasterParams p)
             if (done && qCount == 0 && !reported) {
                 reported = true;
                 if (lane == 0)
-                    atomicAdd(&ctrl[1], 1u);
+                    atomicAdd(&ctrl[doneIdx], 1u);
             }
             if (dskip & 128u) MRX_STAMP(5); else MRX_STAMP(2);
             __syncthreads();
@@ -929,7 +941,7 @@ void bvhTileKernel(const RasterParams p)
             //    end of the round a wave touches only the pixels of its own strip (the
             //    small-triangle walks ended at the barrier), so no barrier separates this
             //    pass from the resolve below.
-            const bool allDone = rflu(ctrl[1]) == (uint32_t)kBvhWaves;
+            const bool allDone = rflu(ctrl[doneIdx]) == (uint32_t)kBvhWaves;
             // The record table lives on from round to round and from pass to pass until it is
             // full (records are per triangle, not per TLAS pass): only then are the round's
             // winners resolved and stashed and the table started afresh.  A round that ended on
@@ -943,8 +955,12 @@ void bvhTileKernel(const RasterParams p)
             const uint32_t recCount = rflu(ctrl[0 + par]);
             const bool tableReset = recCount >= kUsable || (allDone && recCount > kUsable / 2u);
             if (threadIdx.x == 0) {                                   // the next round's counters
-                ctrl[0 + (par ^ 4u)] = tableReset ? 0u : recCount;
+                // (the tile's last round: the next tile of the group starts with an empty table and
+                // counts its finished waves in the other counter, cleared here, two barriers ahead of its use)
+                ctrl[0 + (par ^ 4u)] = (tableReset || (allDone && lastPass)) ? 0u : recCount;
                 ctrl[2 + (par ^ 4u)] = 0u;
+                if (allDone && lastPass)
+                    ctrl[doneIdx ^ 2u] = 0u;
             }
             {
                 const uint32_t listed = min(rflu(ctrl[2 + par]), (uint32_t)kBigCap);
@@ -1023,7 +1039,7 @@ void bvhTileKernel(const RasterParams p)
             //    done, no further pass -- leaves the loops and resolves + outputs in one go below;
             //    a round that filled the record table stashes its winners in the tensors, because
             //    the table is reused from here on.  Nothing resolved is carried in registers.
-            if (allDone && passBase + passInst >= i1)
+            if (allDone && lastPass)
                 break;
             if (tableReset) {
                 // (the kernel's only argument sits at offset 0 of the kernel-argument segment)
@@ -1039,19 +1055,35 @@ void bvhTileKernel(const RasterParams p)
             }
             __syncthreads();
         }
-    }
-    if (i0 >= i1)
-        __syncthreads();                              // an empty world: only the cleared depth buffer
-
-    // ---- the tile's last resolve + output: depth = 1/best (v_rcp_f32, <= 1 ulp), one
-    //      16-byte store per tensor and half
-    if (dskip & 1u)
-        return;
-    if (!(dskip & 128u)) MRX_STAMP(5);
-    {
-        const ResolveArgs ra = { p.rgb, p.depth, p.ids, p.texels, p.nfast, p.nslow, p.writeThrough };
-        resolveStrip<IDS, TEX, TW, TH, true>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
-    }
+        if (!lastPass)
+            break;                                    // on to the next TLAS pass of this (only) tile
+        // ---- the tile's last resolve + output: depth = 1/best (v_rcp_f32, <= 1 ulp), one
+        //      16-byte store per tensor and half
+        if (!(dskip & 1u)) {
+            if (!(dskip & 128u)) MRX_STAMP(5);
+            KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(pk));
+            const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
+            resolveStrip<IDS, TEX, TW, TH, true>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
+        }
+        if (++tile >= lastTile)
+            break;
+        // ---- the next tile of the group: this wave's strip of the depth buffer is cleared (nobody else
+        //      touches it between the barrier ahead of the large pass and the one below), the rectangle
+        //      moves on, the traversal state starts over; the TLAS, the view constants and the light
+        //      direction stay.  One barrier: every strip is clear before anyone merges into it.
+        for (int i = lane; i < TW * 8; i += kWave)
+            zbuf[8 * wave * TW + i] = packHit(invFar, 0u);
+        tileX0 = (tile % tilesFast) * TW;
+        tileY0 = (tile / tilesFast) * TH;
+        TX0 = (float)tileX0; TX1 = (float)(tileX0 + TW - 1);
+        TY0 = (float)tileY0; TY1 = (float)(tileY0 + TH - 1);
+        par ^= 4u;
+        doneIdx ^= 2u;
+        __syncthreads();
+        }
+        passBase += passInst;
+    } while (passBase < i1);
     MRX_STAMP(6);
 #undef MRX_STAMP
 }
@@ -1080,7 +1112,9 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     const bool tex = p.anyTextured != 0;
     // tile shape: p.bvhTile = 0 (64x64), 1 (64x32: TW 64, TH 32), 2 (32x32)
     const int tw = p.bvhTile == 2 ? 32 : 64, th = p.bvhTile == 0 ? 64 : 32;
-    const uint32_t items = p.numViews * ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
+    const uint32_t tilesPerView = ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
+    const uint32_t groupTiles = std::max<uint32_t>(1u, std::min<uint32_t>(p.bvhGroupTiles, tilesPerView));
+    const uint32_t items = p.numViews * ((tilesPerView + groupTiles - 1) / groupTiles);
     const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th);
     const dim3 grid(items), block(kWave * (th / 8));
     // The kernel needs more dynamic LDS than the 64 KB a launch may ask for by default.  The

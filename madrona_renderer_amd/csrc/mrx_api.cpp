@@ -915,6 +915,22 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         p.bvhSmallArea = std::max(0, std::min(4096, std::atoi(dbg)));
     if (const char *dbg = std::getenv("MRX_BVH_PASS_INST"))
         p.bvhPassInst = std::min<uint32_t>(512u, std::max<uint32_t>(64u, (uint32_t)std::atoi(dbg) / 64u * 64u));
+    // Views of several tiles whose world fits one TLAS pass: a workgroup renders a run of the view's
+    // tiles over one TLAS build (bvh.hip).  As long a run as leaves one full generation of resident
+    // workgroups (two per CU: 512) -- measured, profiles/r03_bvh_group_tiles.txt: 512 views of 256x256
+    // cube+plane 155 -> 119 us at 16 tiles per group, 1024 views of 128x128 73 -> 62 us at 4, and
+    // every shape loses as soon as the groups no longer fill the chip.
+    p.bvhGroupTiles = 1;
+    if (maxWorldInst <= p.bvhPassInst) {
+        const uint32_t tw = p.bvhTile == 2 ? 32 : 64, thh = p.bvhTile == 0 ? 64 : 32;
+        const uint32_t tpv = ((nfast + tw - 1) / tw) * ((nslow + thh - 1) / thh);
+        uint32_t g = 1;
+        while (g < 16u && g * 2u <= tpv && (uint64_t)nviews * ((tpv + 2u * g - 1) / (2u * g)) >= 512u)
+            g *= 2;
+        p.bvhGroupTiles = std::max(1u, g);
+        if (const char *dbg = std::getenv("MRX_BVH_GROUP_TILES"))
+            p.bvhGroupTiles = (uint32_t)std::max(1, std::min((int)tpv, std::atoi(dbg)));
+    }
 
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;

@@ -141,6 +141,9 @@ struct RasterParams {
     int32_t bvhTile;                 // tile of a workgroup: 0 = 64x64, 1 = 64 wide x 32, 2 = 32x32 (MRX_BVH_TILE)
     int32_t bvhSmallArea;            // boxes of up to this many pixels are walked by their triangle's lane
     int32_t bvhClassify;             // 64x64 tiles: the instantiation that classifies listed triangles per strip
+    // tiles of a view one workgroup renders in turn over one TLAS build (1 when a world needs several
+    // TLAS passes; filled in by the host, MRX_BVH_GROUP_TILES overrides)
+    uint32_t bvhGroupTiles;
 };
 
 // Default dispatch: worlds of this many triangles and more take the BVH path
