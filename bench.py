@@ -44,6 +44,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # untimed renders before the warm-up (clocks leave idle only under load); reported as `settle_s`
 SETTLE_S = float(os.environ.get("MRX_BENCH_SETTLE_S", "0.25"))
+# renders per host wait during the settle: long batches keep the card under continuous load (batches of 100
+# leave a gap every 2.3 ms, and a K = 20 region measured right after them ran 0.5 - 1 us per step slower:
+# profiles/r03_k20.txt)
+SETTLE_BATCH = int(os.environ.get("MRX_BENCH_SETTLE_BATCH", "2000"))
 STRONG_WORLDS = 16384    # BASELINE.json configs[3]
 
 
@@ -219,8 +223,8 @@ def settle(r, seconds):
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < seconds:
-        r.time_renders(100)
-        n += 100
+        r.time_renders(SETTLE_BATCH)
+        n += SETTLE_BATCH
     return n
 
 
@@ -392,6 +396,7 @@ def run_rank(a):
         "warmup": a.warmup,
         "settle_s": SETTLE_S,
         "settle_renders": settle_renders,
+        "settle_batch": SETTLE_BATCH,
         "ms_per_step": wall * 1000.0 / a.steps,
         "higher_is_better": True,
         "scaling": "weak",
