@@ -162,6 +162,23 @@ def test_cubes_spawned_into_a_running_renderer(native, kind):
     got, ref = fetch(r), fs.render()
     assert_parity(got, ref)
     assert ref["tri_id"].max() >= (14 if kind != "bvh" else 362)              # the new cubes' triangles are visible
+    # ... and the same picture as a renderer-independent restatement: a STATIC scene that holds the spawned
+    # cubes as ordinary instances from the start (no spare rows, no refresh on either side)
+    static = scenes.SceneDesc(**{k: getattr(d, k) for k in d.__dataclass_fields__})
+    static.max_instances_per_world = 0
+    inst, worlds = [], []
+    for w in range(d.num_worlds):
+        lo, hi = int(fs.world_inst_start[w]), int(fs.world_inst_start[w + 1])
+        rows_w = [i for i in range(lo, hi) if fs.inst_obj0[i] >= 0]
+        worlds.append((len(rows_w), len(inst), d.worlds[w][2], d.worlds[w][3]))
+        for i in rows_w:
+            inst.append((tuple(float(x) for x in fs.inst_pos[i]), tuple(float(x) for x in fs.inst_rot[i]),
+                         tuple(float(x) for x in fs.inst_scale[i]), int(fs.inst_obj0[i])))
+    static.instances, static.worlds = inst, worlds
+    ref_static = render_oracle(static)
+    for k in ("rgb", "tri_id", "segmask"):
+        assert np.array_equal(ref[k], ref_static[k]), k
+    assert np.array_equal(ref["depth"], ref_static["depth"])
     # hide one again by sign, swap the geometry of another (cube -> plane object 1), refresh
     fs.inst_obj[rows[0]] = -1
     fs.inst_obj[rows[1]] = 1
