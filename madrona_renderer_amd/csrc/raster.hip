@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock)
 void rasterBruteKernel(const RasterParams p)
 {
     __shared__ WaveLds lds[kWavesPerBlock];
+    touchKernelArguments();
     const int wave = threadIdx.x / kWave;
     const int lane = threadIdx.x % kWave;
     TileCtx t;
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, 3)
 void rasterChunkedKernel(const RasterParams p)
 {
     __shared__ TileLds lds;
+    touchKernelArguments();
     const int wave = threadIdx.x / kWave;
     const int lane = threadIdx.x % kWave;
     TileCtx t;
@@ -650,6 +652,7 @@ void rasterGroupKernel(const RasterParams p)
 {
     __shared__ GroupLds<SLOTS> lds;
     constexpr int kBackground = GroupLds<SLOTS>::kBackground;
+    touchKernelArguments();
     // readfirstlane: the compiler cannot see that threadIdx.x / 64 is
     // wave-uniform and would predicate every `wave` branch instead of jumping
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
