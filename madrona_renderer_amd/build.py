@@ -76,6 +76,9 @@ def build_hip(force=False, verbose=False, extra_flags=()):
                # pays for it in v_mov shuffles and ~40 extra VGPRs (no rate gain
                # on gfx950: packed f32 issues at the scalar-f32 rate)
                "-fno-slp-vectorize",
+               # the command processor writes the first 12 dwords of a kernel's arguments into SGPRs at wave
+               # launch: the group kernel's argument header (raster.hpp GroupHeader)
+               "-mllvm", "-amdgpu-kernarg-preload-count=12",
                "-Wall", "-Wno-unused-function"]
         cmd += list(extra_flags)
         # e.g. MRX_EXTRA_HIPCC_FLAGS=-DMRX_BVH_DIAG=1 python -m madrona_renderer_amd.build --force

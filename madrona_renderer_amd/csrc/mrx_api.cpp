@@ -238,6 +238,10 @@ struct mrx_renderer {
     DevBuf<uint32_t> texels;
     DevBuf<mrx::WorldTri> viewTris;
     DevBuf<uint32_t> viewTriCount;
+    // the pose tensors are slices of one block, the geometry tables of another, at offsets that follow
+    // from the counts (raster.hpp poseLayout / geomMatsOffset): the group kernel's fast prologue derives
+    // their addresses from two base pointers that reach it preloaded in SGPRs
+    DevBuf<uint8_t> poseBlock, geomBlock;
     DevBuf<float> instPos, instRot, instScale, camPos, camRot;
     DevBuf<int32_t> instObj;
     DevBuf<uint32_t> rgb;
@@ -298,6 +302,7 @@ struct mrx_renderer {
         viewTris.release(); viewTriCount.release();
         instPos.release(); instRot.release(); instScale.release();
         camPos.release(); camRot.release(); instObj.release();
+        poseBlock.release(); geomBlock.release();
         rgb.release(); depth.release(); ids.release(); stamps.release();
         if (xccHost) (void)hipHostFree(xccHost);
         bvhNodes.release(); bvhLeafTris.release(); worldInstStart.release();
@@ -741,8 +746,18 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     r.boundObj = instObj;
 
     // ---- upload what never changes shape
-    MRX_HIP(r.tris.upload(tris));
-    MRX_HIP(r.triMats.upload(triMats));
+    {
+        // geometry block: ObjTri[pool], then TriMat[pool] at the next 256-byte boundary
+        const uint32_t pool = (uint32_t)tris.size();
+        const size_t matsOff = geomMatsOffset(pool);
+        MRX_HIP(r.geomBlock.alloc(matsOff + (size_t)pool * sizeof(TriMat) + 256));
+        r.tris.view(r.geomBlock.ptr, pool);
+        r.triMats.view(r.geomBlock.ptr + matsOff, pool);
+        if (pool) {
+            MRX_HIP(hipMemcpy(r.tris.ptr, tris.data(), (size_t)pool * sizeof(ObjTri), hipMemcpyHostToDevice));
+            MRX_HIP(hipMemcpy(r.triMats.ptr, triMats.data(), (size_t)pool * sizeof(TriMat), hipMemcpyHostToDevice));
+        }
+    }
     MRX_HIP(r.textures.upload(texDescs));
     MRX_HIP(r.texels.upload(texels));
     r.triMatsHost = triMats;
@@ -764,12 +779,29 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     MRX_HIP(r.bvhLeafTris.upload(blas.leafTris));
     MRX_HIP(r.worldInstStart.upload(worldInstStart));
     MRX_HIP(r.viewWorld.upload(viewWorld));
-    MRX_HIP(r.instPos.upload(instPos));
-    MRX_HIP(r.instRot.upload(instRot));
-    MRX_HIP(r.instScale.upload(instScale));
-    MRX_HIP(r.instObj.upload(instObj));
-    MRX_HIP(r.camPos.upload(camPos));
-    MRX_HIP(r.camRot.upload(camRot));
+    {
+        // pose block (the exported, user-mutable tensors are slices of it)
+        const uint32_t nv = (uint32_t)viewWorld.size(), ni = (uint32_t)instObj.size();
+        const PoseLayout lay = poseLayout(nv, ni);
+        MRX_HIP(r.poseBlock.alloc((size_t)lay.total + 256));
+        MRX_HIP(hipMemset(r.poseBlock.ptr, 0, (size_t)lay.total + 256));
+        uint8_t *b = r.poseBlock.ptr;
+        r.camRot.view(b + lay.camRot, camRot.size());
+        r.camPos.view(b + lay.camPos, camPos.size());
+        r.instRot.view(b + lay.instRot, instRot.size());
+        r.instPos.view(b + lay.instPos, instPos.size());
+        r.instScale.view(b + lay.instScale, instScale.size());
+        r.instObj.view(b + lay.instObj, instObj.size());
+        auto up = [](void *dst, const void *src, size_t bytes) {
+            return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+        };
+        MRX_HIP(up(r.camRot.ptr, camRot.data(), camRot.size() * 4));
+        MRX_HIP(up(r.camPos.ptr, camPos.data(), camPos.size() * 4));
+        MRX_HIP(up(r.instRot.ptr, instRot.data(), instRot.size() * 4));
+        MRX_HIP(up(r.instPos.ptr, instPos.data(), instPos.size() * 4));
+        MRX_HIP(up(r.instScale.ptr, instScale.data(), instScale.size() * 4));
+        MRX_HIP(up(r.instObj.ptr, instObj.data(), instObj.size() * 4));
+    }
 
     const bool rt = cfg.render_mode == MRX_MODE_RAYTRACER;
     const uint32_t W = cfg.view_width;
@@ -799,6 +831,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.triMats = r.triMats.ptr;
     p.textures = r.textures.ptr;
     p.texels = r.texels.ptr;
+    p.poseBlock = reinterpret_cast<const char *>(r.poseBlock.ptr);
+    p.geomBlock = reinterpret_cast<const char *>(r.geomBlock.ptr);
+    p.numInstances = (uint32_t)instObj.size();
+    p.poolTris = (uint32_t)tris.size();
     p.instPos = r.instPos.ptr;
     p.instRot = r.instRot.ptr;
     p.instScale = r.instScale.ptr;

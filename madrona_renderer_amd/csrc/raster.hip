@@ -19,6 +19,7 @@
 // separate restatement of the same spec and is never linked here.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 
 #include "raster.hpp"
 #include "raster_dev.hpp"
@@ -635,6 +636,16 @@ __device__ __forceinline__ void storeBackground(const RasterParams &p, uint32_t 
     }
 }
 
+// What the group kernel's set-up reads per triangle (instanceTransform / setupTriangleCore are templates over
+// the parameter type): pointers from the preloaded header or from RasterParams, scalars from RasterParams.
+struct GroupSetupArgs {
+    const ObjTri *tris;
+    const TriMat *triMats;
+    const float *instPos, *instRot, *instScale;
+    float sx, ox, sz, oz, s6bPad, ambient, diffuse;
+    int32_t transposed;
+};
+
 // Waves per workgroup of the group kernel: eight for untextured scenes (more
 // waves in flight absorb the stalls of a saturated store path), four for the
 // textured variant (its texel loads cost registers and vmcnt drains).
@@ -645,19 +656,40 @@ constexpr int groupWaves(bool tex) { return tex ? 4 : 8; }
 // instantiations, chosen per launch by the host, because any extra state in this kernel's
 // work loop costs more than the split gains (59 of 64 VGPRs, SGPRs spilled): XMODE 0 is
 // the kernel as it always was.
-template <bool IDS, int SLOTS, bool TEX, int XMODE = 0>
-// (the second bound is waves per SIMD; 256-slot groups are LDS-limited to 3 per CU)
-__global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? (SLOTS > 128 ? 3 : 4) : (SLOTS > 128 ? 6 : 8))
-void rasterGroupKernel(const RasterParams p)
+// FAST (16-slot instantiations; chosen by the host for uniform worlds of one-tile views without diagnostics): the
+// set-up waves' path to their first pose loads reads nothing but the twelve leading header arguments (GroupHeader,
+// raster.hpp), which the command processor preloads into SGPRs (-mllvm -amdgpu-kernarg-preload-count=12): the loads
+// go out without a round trip to the argument block; `p` is read for what comes after.
+template <bool IDS, int SLOTS, bool TEX, int XMODE, bool FAST>
+__device__ __forceinline__ void groupKernelBody(const char *hPose, const char *hGeom, uint32_t hViews, uint32_t hInstances,
+                                                uint32_t hPool, uint32_t hShape, uint32_t hGroups, uint32_t hPrefix,
+                                                uint32_t hFirst01, uint32_t hFirst23, const RasterParams p)
 {
     __shared__ GroupLds<SLOTS> lds;
     constexpr int kBackground = GroupLds<SLOTS>::kBackground;
-    touchKernelArguments();
     // readfirstlane: the compiler cannot see that threadIdx.x / 64 is
     // wave-uniform and would predicate every `wave` branch instead of jumping
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
-    const uint32_t tilesPerView = p.tilesFast * p.tilesSlow;
+    // (FAST: the set-up waves -- 0 and 1 -- have what they need in SGPRs and must not wait for the argument block;
+    // the other waves touch it for the whole CU, whose scalar cache they share)
+    if (!FAST || wave >= 2)
+        touchKernelArguments<(FAST ? 48 : 0) + sizeof(RasterParams)>();
+    // what the prologue reads of the arguments: from the preloaded header (FAST) or from `p`
+    const uint32_t aNumViews = FAST ? hViews : p.numViews;
+    const uint32_t aGrpViews = FAST ? (hShape & 255u) : p.grpViews;
+    const uint32_t aXcdSkew = FAST ? ((hShape >> 8) & 15u) : p.xcdSkew;
+    const uint32_t aXcdRotate = FAST ? ((hShape >> 12) & 1u) : p.xcdRotate;
+    const uint32_t aGrpPerView = FAST ? 1u : p.grpPerView;
+    const uint32_t aGrid = FAST ? hGroups : gridDim.x;
+    const uint32_t aUniInstances = FAST ? ((hShape >> 13) & 7u) : p.uniInstances;
+    const uint32_t aUniCams = FAST ? ((hShape >> 16) & 255u) : p.uniCamsPerWorld;
+    const uint32_t dskip = FAST ? 0u : p.debugSkip;           // (the host never picks FAST with diagnostics on)
+    const PoseLayout lay = poseLayout(hViews, hInstances);
+    const float *aCamRot = FAST ? reinterpret_cast<const float *>(hPose + lay.camRot) : p.camRot;
+    const float *aCamPos = FAST ? reinterpret_cast<const float *>(hPose + lay.camPos) : p.camPos;
+    const int32_t *aInstObj = FAST ? reinterpret_cast<const int32_t *>(hPose + lay.instObj) : p.instObj;
+    const uint32_t tilesPerView = FAST ? 1u : p.tilesFast * p.tilesSlow;
     // ---- which views / tiles this workgroup owns (launchRaster):
     //  A  grpPerView == 1: grpViews whole views (all their tiles);
     //  B  otherwise: grpChunkTiles tiles of one view.
@@ -674,24 +706,24 @@ void rasterGroupKernel(const RasterParams p)
     // picks the instantiation by the parity workgroup 0 reported in an earlier launch
     // of this renderer -- every workgroup of a launch runs the same code, so the trade
     // is consistent whatever the hardware does; a stale value costs speed, never pixels.
-    const uint32_t blk = ((XMODE & 1) && SLOTS == 16 && p.xcdSkew && (blockIdx.x ^ 1u) < gridDim.x)
+    const uint32_t blk = ((XMODE & 1) && SLOTS == 16 && aXcdSkew && (blockIdx.x ^ 1u) < aGrid)
                              ? blockIdx.x ^ 1u : blockIdx.x;
     // workgroup 0 reports where it runs: a host-mapped word, written by the last wave,
     // which issues no loads during set-up -- the slow write sits ahead of nothing
     if ((XMODE & 2) && blockIdx.x == 0 && threadIdx.x == (groupWaves(TEX) - 1) * kWave && p.xccReport)
         *p.xccReport = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
     uint32_t bid = blk;
-    if (p.xcdRotate && (bid | 7u) < gridDim.x)
+    if (aXcdRotate && (bid | 7u) < aGrid)
         bid = (bid & ~7u) | ((bid + 2u * (bid >> 3)) & 7u);
-    if (p.grpPerView == 1) {
-        firstView = bid * p.grpViews;
-        groupViews = p.grpViews;
+    if (aGrpPerView == 1) {
+        firstView = bid * aGrpViews;
+        groupViews = aGrpViews;
         firstTile = 0;
         groupTiles = groupViews * tilesPerView;
     } else {
-        firstView = bid / p.grpPerView;
+        firstView = bid / aGrpPerView;
         groupViews = 1;
-        firstTile = (bid - firstView * p.grpPerView) * p.grpChunkTiles;
+        firstTile = (bid - firstView * aGrpPerView) * p.grpChunkTiles;
         groupTiles = min(p.grpChunkTiles, tilesPerView - firstTile);
     }
     // XCD-aware split (see launchRaster; one-tile views, four per group):
@@ -700,22 +732,22 @@ void rasterGroupKernel(const RasterParams p)
     // even = on an even XCD) share the view between their two runs of four: the odd
     // one leaves its first p.xcdSkew strips to the even one (both set the view up).
     uint32_t firstStrip = 0, numStrips = groupTiles * 8;
-    if (SLOTS == 16 && p.xcdSkew) {
+    if (SLOTS == 16 && aXcdSkew) {
         if (blk & 1u) {
-            firstStrip = p.xcdSkew;
-            numStrips -= p.xcdSkew;
+            firstStrip = aXcdSkew;
+            numStrips -= aXcdSkew;
         } else {
             groupViews += 1;
             groupTiles += 1;
-            numStrips += p.xcdSkew;
+            numStrips += aXcdSkew;
         }
     }
     const int groupRecs = (int)groupViews * SLOTS;
     const int numPairs = (int)groupTiles * SLOTS;
     const float invNear = p.invNear, invFar = p.invFar;
-    if (p.debugSkip & 16u)
+    if (dskip & 16u)
         return;                                   // timing aid: bare launch
-    unsigned long long *stamps = (p.debugStamps && wave < 4)
+    unsigned long long *stamps = (!FAST && p.debugStamps && wave < 4)
         ? p.debugStamps + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
 #define MRX_STAMP(i)                                                           \
     do {                                                                       \
@@ -740,7 +772,7 @@ void rasterGroupKernel(const RasterParams p)
         lds.tileInfo[lane][0] = firstView + vi;
         lds.tileInfo[lane][1] = (tile - ty * p.tilesFast) * 64u;
         lds.tileInfo[lane][2] = ty * 64u;
-        lds.tileInfo[lane][3] = (firstView + vi < p.numViews ? kTileValid : 0u) | ((vi * SLOTS) << 8);
+        lds.tileInfo[lane][3] = (firstView + vi < aNumViews ? kTileValid : 0u) | ((vi * SLOTS) << 8);
     }
     // ... and the order of the work items.  One-tile views: strip by strip
     // across the views, top strips first -- strips above the horizon cost
@@ -767,30 +799,32 @@ void rasterGroupKernel(const RasterParams p)
         const int rec = wave * kWave + lane;
         const int vi = rec / SLOTS, k = rec % SLOTS;
         const bool recOk = rec < groupRecs;
-        const bool viewOk = recOk && firstView + vi < p.numViews;
+        const bool viewOk = recOk && firstView + vi < aNumViews;
         const uint32_t view = viewOk ? firstView + vi : 0u;
         // everything addressed by the view index is requested up front; the
         // pose / geometry rows one level down follow as soon as wt arrives --
         // or at once, when the draw list is arithmetic (uniform worlds)
         WorldTri wt;
         uint32_t numTris;
-        if (p.uniInstances) {
+        if (aUniInstances) {
             const uint32_t kk = (uint32_t)k;
-            const uint32_t li = (kk >= p.uniPrefix[1] ? 1u : 0u) + (kk >= p.uniPrefix[2] ? 1u : 0u) +
-                                (kk >= p.uniPrefix[3] ? 1u : 0u);
-            const uint32_t pre = li == 0 ? p.uniPrefix[0] : li == 1 ? p.uniPrefix[1]
-                               : li == 2 ? p.uniPrefix[2] : p.uniPrefix[3];
-            const uint32_t first = li == 0 ? p.uniFirstTri[0] : li == 1 ? p.uniFirstTri[1]
-                                 : li == 2 ? p.uniFirstTri[2] : p.uniFirstTri[3];
+            // (FAST: the table rides in the header, eight / sixteen bits per entry)
+            const uint32_t pre1 = FAST ? (hPrefix & 255u) : p.uniPrefix[1], pre2 = FAST ? ((hPrefix >> 8) & 255u) : p.uniPrefix[2];
+            const uint32_t pre3 = FAST ? ((hPrefix >> 16) & 255u) : p.uniPrefix[3], pre4 = FAST ? (hPrefix >> 24) : p.uniPrefix[4];
+            const uint32_t ft0 = FAST ? (hFirst01 & 0xFFFFu) : p.uniFirstTri[0], ft1 = FAST ? (hFirst01 >> 16) : p.uniFirstTri[1];
+            const uint32_t ft2 = FAST ? (hFirst23 & 0xFFFFu) : p.uniFirstTri[2], ft3 = FAST ? (hFirst23 >> 16) : p.uniFirstTri[3];
+            const uint32_t li = (kk >= pre1 ? 1u : 0u) + (kk >= pre2 ? 1u : 0u) + (kk >= pre3 ? 1u : 0u);
+            const uint32_t pre = li == 0 ? 0u : li == 1 ? pre1 : li == 2 ? pre2 : pre3;
+            const uint32_t first = li == 0 ? ft0 : li == 1 ? ft1 : li == 2 ? ft2 : ft3;
             // integer divisions cost ~25 VALU each: a real (scalar) branch
             // around this one for the common one-camera-per-world case
             uint32_t world = view;
-            if (p.uniCamsPerWorld != 1)
-                world = view / p.uniCamsPerWorld;
-            wt.inst = world * p.uniInstances + li;
+            if (aUniCams != 1)
+                world = view / aUniCams;
+            wt.inst = world * aUniInstances + li;
             wt.tri = first + (kk - pre);
-            numTris = viewOk ? p.uniPrefix[4] : 0u;
-            if (kk >= p.uniPrefix[4]) {           // idle slot: keep the loads in range
+            numTris = viewOk ? pre4 : 0u;
+            if (kk >= pre4) {                     // idle slot: keep the loads in range
                 wt.inst = 0;
                 wt.tri = 0;
             }
@@ -801,11 +835,11 @@ void rasterGroupKernel(const RasterParams p)
         }
         ViewConst vc;
         {
-            const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * view);
+            const float4 q = *reinterpret_cast<const float4 *>(aCamRot + 4 * view);
             quatToMat(q.x, q.y, q.z, q.w, vc.Rc);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                vc.c[r] = p.camPos[3 * view + r];
+                vc.c[r] = aCamPos[3 * view + r];
                 vc.lv[r] = dot3(vc.Rc[0][r], vc.Rc[1][r], vc.Rc[2][r],
                                 p.toLight[0], p.toLight[1], p.toLight[2]);
             }
@@ -818,15 +852,26 @@ void rasterGroupKernel(const RasterParams p)
         MRX_STAMP(1);
         if (recOk) {
             lds.shade[rec][1] = __int_as_float(-1);
-            if ((uint32_t)k < numTris && !(p.debugSkip & 8u))
-                valid = setupTriangle(p, vc, wt, k, c, lds.shade[rec], lds.cold[rec]);
+            if ((uint32_t)k < numTris && !(dskip & 8u)) {
+                // the pose / geometry rows through pointers that come from the header (FAST) or from `p`
+                const GroupSetupArgs sa = {
+                    FAST ? reinterpret_cast<const ObjTri *>(hGeom) : p.tris,
+                    FAST ? reinterpret_cast<const TriMat *>(hGeom + geomMatsOffset(hPool)) : p.triMats,
+                    FAST ? reinterpret_cast<const float *>(hPose + lay.instPos) : p.instPos,
+                    FAST ? reinterpret_cast<const float *>(hPose + lay.instRot) : p.instRot,
+                    FAST ? reinterpret_cast<const float *>(hPose + lay.instScale) : p.instScale,
+                    p.sx, p.ox, p.sz, p.oz, p.s6bPad, p.ambient, p.diffuse, p.transposed };
+                InstXform x;
+                instanceTransform(sa, vc, wt.inst, x);
+                valid = setupTriangleCore<true>(sa, vc.lv, x, wt.tri, aInstObj[wt.inst], k, c, lds.shade[rec], lds.cold[rec]);
+            }
             MRX_STAMP(2);
             float4 *dst = reinterpret_cast<float4 *>(lds.planes[rec]);
             dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
             dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
             dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
             dst[3] = make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1);
-            lds.live[rec] = (valid && !(p.debugSkip & 4u)) ? 1u : 0u;
+            lds.live[rec] = (valid && !(dskip & 4u)) ? 1u : 0u;
         }
         if (rec == 0) {
             lds.nextItem = 0;
@@ -965,7 +1010,7 @@ void rasterGroupKernel(const RasterParams p)
                 best[b] = invFar;
                 bid[b] = kBackground * 16;
             }
-            if (!(p.debugSkip & 2u)) {
+            if (!(dskip & 2u)) {
 #pragma unroll
                 for (int sub = 0; sub < SUBS; ++sub) {
                     if (SUBS > 1 && act[sub] == 0)
@@ -990,6 +1035,26 @@ void rasterGroupKernel(const RasterParams p)
         stamps[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                     (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #undef MRX_STAMP
+}
+
+// The two entry points of the body: the plain one (arguments = RasterParams, as every other kernel here) and the
+// FAST one with the preloaded header in front.
+template <bool IDS, int SLOTS, bool TEX, int XMODE = 0>
+// (the second bound is waves per SIMD; 256-slot groups are LDS-limited to 3 per CU)
+__global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? (SLOTS > 128 ? 3 : 4) : (SLOTS > 128 ? 6 : 8))
+void rasterGroupKernel(const RasterParams p)
+{
+    groupKernelBody<IDS, SLOTS, TEX, XMODE, false>(nullptr, nullptr, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, p);
+}
+
+template <bool IDS, bool TEX, int XMODE>
+__global__ __launch_bounds__(kWave *groupWaves(TEX), TEX ? 4 : 8)
+void rasterGroupKernelFast(const char *hPose, const char *hGeom, uint32_t hViews, uint32_t hInstances, uint32_t hPool,
+                           uint32_t hShape, uint32_t hGroups, uint32_t hPrefix, uint32_t hFirst01, uint32_t hFirst23,
+                           const RasterParams p)
+{
+    groupKernelBody<IDS, 16, TEX, XMODE, true>(hPose, hGeom, hViews, hInstances, hPool, hShape, hGroups, hPrefix, hFirst01,
+                                               hFirst23, p);
 }
 
 }  // namespace
@@ -1084,9 +1149,40 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
             q.xcdRotate = p.xcdRotateWanted ? 1u : 0u;
         const dim3 grid(numGroups);
         const dim3 gblock(kWave * groupWaves(p.anyTextured != 0));
+        // The argument header (GroupHeader, raster.hpp) goes along with every launch; the FAST instantiations --
+        // 16 slots, one-tile views, uniform worlds whose table fits the header, no diagnostics -- read nothing else
+        // ahead of their pose loads.
+        GroupHeader h {};
+        h.pose = p.poseBlock;
+        h.geom = p.geomBlock;
+        h.views = p.numViews;
+        h.instances = p.numInstances;
+        h.poolTris = p.poolTris;
+        h.groups = numGroups;
+        bool fast = slots == 16 && tpv == 1 && gpv == 1 && p.uniInstances != 0 && p.uniCamsPerWorld < 256 && vg < 256 &&
+                    p.poseBlock && p.geomBlock && p.debugSkip == 0 && p.debugStamps == nullptr && p.uniPrefix[4] < 256;
+        for (int i = 0; i < 4 && fast; ++i)
+            fast = p.uniFirstTri[i] < 65536u;
+        if (const char *dbg = std::getenv("MRX_GROUP_FAST"))      // 0: never (A/B and tests)
+            fast = fast && std::atoi(dbg) != 0;
+        if (fast) {
+            h.shape = vg | (q.xcdSkew << 8) | (q.xcdRotate << 12) | (p.uniInstances << 13) | (p.uniCamsPerWorld << 16) | (1u << 31);
+            h.prefix = p.uniPrefix[1] | (p.uniPrefix[2] << 8) | (p.uniPrefix[3] << 16) | (p.uniPrefix[4] << 24);
+            h.first01 = p.uniFirstTri[0] | (p.uniFirstTri[1] << 16);
+            h.first23 = p.uniFirstTri[2] | (p.uniFirstTri[3] << 16);
+        }
+#define MRX_GROUP_ARGS h.pose, h.geom, h.views, h.instances, h.poolTris, h.shape, h.groups, h.prefix, h.first01, h.first23, q
 #define MRX_GROUP_X(S, X)                                                      \
     do {                                                                       \
-        if (p.anyTextured) {                                                   \
+        if (fast && S == 16) {                                                 \
+            if (p.anyTextured) {                                               \
+                if (ids) rasterGroupKernelFast<true, true, X><<<grid, gblock, 0, stream>>>(MRX_GROUP_ARGS);   \
+                else     rasterGroupKernelFast<false, true, X><<<grid, gblock, 0, stream>>>(MRX_GROUP_ARGS);  \
+            } else {                                                           \
+                if (ids) rasterGroupKernelFast<true, false, X><<<grid, gblock, 0, stream>>>(MRX_GROUP_ARGS);  \
+                else     rasterGroupKernelFast<false, false, X><<<grid, gblock, 0, stream>>>(MRX_GROUP_ARGS); \
+            }                                                                  \
+        } else if (p.anyTextured) {                                            \
             if (ids) rasterGroupKernel<true, S, true, X><<<grid, gblock, 0, stream>>>(q);   \
             else     rasterGroupKernel<false, S, true, X><<<grid, gblock, 0, stream>>>(q);  \
         } else {                                                               \
@@ -1107,6 +1203,7 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         else if (slots == 64) MRX_GROUP(64);
         else if (slots == 128) MRX_GROUP(128);
         else MRX_GROUP(256);
+#undef MRX_GROUP_ARGS
 #undef MRX_GROUP_X
 #undef MRX_GROUP
     }

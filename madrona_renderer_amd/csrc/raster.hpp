@@ -71,6 +71,10 @@ struct RasterParams {
     uint32_t uniCamsPerWorld;
     uint32_t uniPrefix[5];
     uint32_t uniFirstTri[4];
+    // the blocks the pose tensors / geometry tables are slices of (GroupHeader; filled in by mrx_create)
+    const char *poseBlock;
+    const char *geomBlock;
+    uint32_t numInstances, poolTris;
     // pose state (the exported, mutable tensors)
     const float *instPos;            // [I][3]
     const float *instRot;            // [I][4] w,x,y,z
@@ -144,6 +148,48 @@ struct RasterParams {
     // tiles of a view one workgroup renders in turn over one TLAS build (1 when a world needs several
     // TLAS passes; filled in by the host, MRX_BVH_GROUP_TILES overrides)
     uint32_t bvhGroupTiles;
+};
+
+// ---- the argument header of the group kernel's fast prologue (raster.hip, FAST) -------------------------------------
+// The command processor can write the first dwords of a kernel's argument block into SGPRs at wave launch
+// (-mllvm -amdgpu-kernarg-preload-count): a kernel whose first loads need only those starts them without the
+// s_load round trip to the argument block (a fresh copy, hence a cache miss, on every launch: 0.24 us in
+// scripts/micro/kernarg_preload.hip).  Fourteen dwords at most, so everything the set-up waves of a
+// uniform-world, one-tile-per-view launch need ahead of their pose loads is packed into twelve: the pose
+// tensors live in ONE block and the geometry tables in another, at offsets that follow from the counts.
+#if defined(__HIP__) || defined(__HIPCC__)
+#define MRX_HD __host__ __device__
+#else
+#define MRX_HD
+#endif
+struct PoseLayout {
+    uint32_t camRot, camPos, instRot, instPos, instScale, instObj, total;   // byte offsets, 256-byte aligned
+};
+MRX_HD inline uint32_t mrxAlign256(uint32_t x) { return (x + 255u) & ~255u; }
+MRX_HD inline PoseLayout poseLayout(uint32_t views, uint32_t instances)
+{
+    PoseLayout l;
+    l.camRot = 0;
+    l.camPos = l.camRot + mrxAlign256(views * 16u);
+    l.instRot = l.camPos + mrxAlign256(views * 12u);
+    l.instPos = l.instRot + mrxAlign256(instances * 16u);
+    l.instScale = l.instPos + mrxAlign256(instances * 12u);
+    l.instObj = l.instScale + mrxAlign256(instances * 12u);
+    l.total = l.instObj + mrxAlign256(instances * 4u);
+    return l;
+}
+// geometry block: ObjTri[pool] at 0, TriMat[pool] at geomMatsOffset(pool)
+MRX_HD inline uint32_t geomMatsOffset(uint32_t poolTris) { return mrxAlign256(poolTris * 64u); }
+
+struct GroupHeader {
+    const char *pose;        // base of the pose block (poseLayout(views, instances))
+    const char *geom;        // base of the geometry block
+    uint32_t views, instances, poolTris;
+    // grpViews | xcdSkew << 8 | xcdRotate << 12 | uniInstances << 13 | uniCamsPerWorld << 16 | valid << 31
+    uint32_t shape;
+    uint32_t groups;         // workgroups of the launch
+    uint32_t prefix;         // uniPrefix[1..4], eight bits each
+    uint32_t first01, first23;   // uniFirstTri[0..3], sixteen bits each
 };
 
 // Default dispatch: worlds of this many triangles and more take the BVH path

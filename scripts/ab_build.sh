@@ -7,6 +7,6 @@ NAME="$1"; shift
 C="$ROOT/madrona_renderer_amd/csrc"
 mkdir -p "$ROOT/ab"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -mllvm -disable-promote-alloca-to-vector -fno-slp-vectorize -Wall -Wno-unused-function "$@" \
+  -mllvm -disable-promote-alloca-to-vector -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=12 -Wall -Wno-unused-function "$@" \
   "$C/raster.hip" "$C/bvh.hip" "$C/bvh.cpp" "$C/mrx_api.cpp" "$C/assets.cpp" "$C/ktx2.cpp" \
   -lz -ldl -Wl,-rpath,/opt/rocm/lib -o "$ROOT/ab/libmrx_hip.so.$NAME"

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-mllvm", "-disable-promote-alloca-to-vector", "-fno-slp-vectorize"]
+         "-mllvm", "-disable-promote-alloca-to-vector", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=12"]
 
 
 def resources(src, extra=()):
