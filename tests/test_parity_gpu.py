@@ -583,6 +583,33 @@ def test_a_different_nonnegative_object_id_changes_neither_geometry_nor_segmask(
     assert set(np.unique(after["segmask"]).tolist()) <= set(bound.cpu().tolist()) | {-1}
 
 
+@pytest.mark.parametrize("worlds,kw", [(40, {}), (1100, {}), (300, {"textured": True}), (90, {"render_mode": "Raytracer", "textured": True})])
+def test_preloaded_header_entry_point_renders_the_same_bytes(native, monkeypatch, worlds, kw):
+    # The group kernel's fast entry point (argument header preloaded into SGPRs, pose / geometry addresses derived
+    # from two block pointers) against the plain one (MRX_GROUP_FAST=0, read per launch) on uniform 64x64 worlds:
+    # small and chip-filling batches (the XCD-aware split and its trade instantiations), textured, Raytracer, with ids
+    d = scenes.synthetic_scene(worlds, **kw)
+    rt = kw.get("render_mode") == "Raytracer"
+    r = make_product(d, visibility=not rt)
+    ref = render_oracle(d)
+    fast = fetch(r, visibility=not rt, raytracer=rt)
+    assert_parity(fast, ref)
+    monkeypatch.setenv("MRX_GROUP_FAST", "0")
+    for _ in range(3):
+        r.step()
+    plain = fetch(r, visibility=not rt, raytracer=rt)
+    for k in fast:
+        assert np.array_equal(fast[k], plain[k]), k
+    monkeypatch.delenv("MRX_GROUP_FAST")
+    # a multi-camera uniform world (view / cameras-per-world division in the header path)
+    d2 = scenes.synthetic_scene(12)
+    cams = list(d2.cameras)
+    d2.cameras = [c for pq in cams for c in (pq, ((pq[0][0], pq[0][1], pq[0][2] + 1.5), pq[1]))]
+    d2.worlds = [(2, 2 * w, 2, 2 * w) for w in range(12)]
+    r2 = make_product(d2)
+    assert_parity(fetch(r2), render_oracle(d2))
+
+
 def full_ids(fs):
     keep = fs.inst_obj.copy()
     fs.inst_obj[:] = fs.inst_obj0
