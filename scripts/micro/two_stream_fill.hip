@@ -111,6 +111,34 @@ int main(int argc, char **argv)
         if (blockB) { hipFree(blockA); held = blockB; } else held = blockA;
     }
     if (held) hipFree(held);
+    if (argc > 4) {
+        // scan mode (argv[4] = steps of 64 KiB): ONE pair of blocks, kept; the depth tensor slides through its block
+        // in 64 KiB steps.  Does the mode follow the offset inside fixed physical blocks, or only the blocks?
+        const int steps = std::atoi(argv[4]);
+        void *a = nullptr, *b = nullptr;
+        if (hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes + ((size_t)steps << 16) + (1u << 20)) == hipSuccess) {
+            uint32_t *rgb = (uint32_t *)a;
+            printf("scan: rgb %p, depth block %p\n", a, b);
+            for (int st = 0; st < steps; ++st) {
+                uint32_t *depth = (uint32_t *)((char *)b + ((size_t)st << 16));
+                float best = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipEventRecord(e0, 0);
+                    for (int r = 0; r < 20; ++r)
+                        fillTwo<<<grid, 512>>>(rgb, depth, nfast, tilesFast, tilesPerView, nslow, r);
+                    hipEventRecord(e1, 0);
+                    hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (rep) best = std::min(best, ms / 20 * 1e3f);
+                }
+                if (st % 16 == 0) printf("\n  depth offset %5d KiB:", st * 64);
+                printf("%6.1f", best);
+            }
+            printf("\n");
+        }
+        if (a) hipFree(a);
+        if (b) hipFree(b);
+    }
     if (!both.empty()) {
         const float lo = *std::min_element(both.begin(), both.end()), hi = *std::max_element(both.begin(), both.end());
         const float slo = *std::min_element(single.begin(), single.end()), shi = *std::max_element(single.begin(), single.end());
