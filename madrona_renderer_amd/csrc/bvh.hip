@@ -76,7 +76,8 @@ __device__ __forceinline__ int waveInclusiveSum(int v)
 }
 
 // Camera rotation / position of a view and the light direction in its frame (S2, S4).
-__device__ __forceinline__ void loadViewConst(const RasterParams &p, uint32_t view, ViewConst &vc)
+template <typename PARAMS>
+__device__ __forceinline__ void loadViewConst(const PARAMS &p, uint32_t view, ViewConst &vc)
 {
     const float4 q = *reinterpret_cast<const float4 *>(p.camRot + 4 * view);
     quatToMat(q.x, q.y, q.z, q.w, vc.Rc);
@@ -111,7 +112,8 @@ __device__ __forceinline__ void projectCorner(const RasterParams &p, const float
 
 // Image bounds -> padded storage rectangle.  Not `front`: the box reaches the
 // eye plane, its image is unbounded -- always visit.
-__device__ __forceinline__ Rect finishRect(const RasterParams &p, float x0, float x1, float z0,
+template <typename PARAMS>
+__device__ __forceinline__ Rect finishRect(const PARAMS &p, float x0, float x1, float z0,
                                            float z1, bool front)
 {
     const float mx = 1.0f + 4e-3f * fmaxf(fabsf(x0), fabsf(x1));
@@ -134,7 +136,8 @@ __device__ __forceinline__ Rect finishRect(const RasterParams &p, float x0, floa
 // rounding of the sums they come from, the quotients use the near or far side of the
 // sphere whichever widens the interval, and a sphere that reaches the eye plane gives the
 // unbounded rectangle.
-__device__ __forceinline__ Rect sphereRect(const RasterParams &p, const InstXform &x, float4 omin, float4 omax,
+template <typename PARAMS>
+__device__ __forceinline__ Rect sphereRect(const PARAMS &p, const InstXform &x, float4 omin, float4 omax,
                                            float isx, float isz)
 {
     const float c[3] = { 0.5f * (omin.x + omax.x), 0.5f * (omin.y + omax.y), 0.5f * (omin.z + omax.z) };
@@ -405,10 +408,72 @@ __device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long 
     }
 }
 
+// The instance rows [i0, i1) of a view's world
+template <typename PARAMS>
+__device__ __forceinline__ void viewInstances(const PARAMS &p, uint32_t view, uint32_t &i0, uint32_t &i1)
+{
+    // (uniform worlds: arithmetic instead of two dependent loads)
+    if (p.bvhUniInst) {
+        uint32_t world = view;
+        if (p.bvhUniCams != 1)
+            world = view / p.bvhUniCams;
+        i0 = world * p.bvhUniInst;
+        i1 = i0 + p.bvhUniInst;
+    } else {
+        const uint32_t world = p.viewWorld[view];
+        i0 = p.worldInstStart[world];
+        i1 = p.worldInstStart[world + 1];
+    }
+}
+
+// Phase I for chunks chFirst, chFirst + chStep, ... of the nI instances of a pass (rows from passBase on),
+// lane = instance: the TLAS records and rectangles of a view, into the block at `rec` ([passInst][24] records,
+// then [passInst] rectangles).
+template <typename PARAMS>
+__device__ __forceinline__ void tlasChunks(const PARAMS &p, const ViewConst &vc, uint32_t passBase, uint32_t nI,
+                                           uint32_t chFirst, uint32_t chStep, float *rec, uint32_t passInst, float isx,
+                                           float isz, int lane)
+{
+    float4 *const rects = reinterpret_cast<float4 *>(rec + (size_t)passInst * kInstRecDw);
+    for (uint32_t ch = chFirst; ch * kWave < nI; ch += chStep) {
+        const uint32_t li = ch * kWave + (uint32_t)lane;
+        const bool has = li < nI;
+        const uint32_t row = passBase + (has ? li : 0u);
+        const int32_t obj = p.instObj[row];
+        const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + row);
+        const float4 o0 = oi[0], omin = oi[1], omax = oi[2];
+        const uint32_t kBase = p.instKBase[row];
+        InstXform x;
+        instanceTransform(p, vc, row, x);
+        Rect r = sphereRect(p, x, omin, omax, isx, isz);
+        if (!(obj >= 0) || __float_as_uint(o0.y) == 0u) {    // nothing to draw: a rectangle nothing meets
+            r.x0 = r.y0 = __builtin_inff();
+            r.x1 = r.y1 = -__builtin_inff();
+        }
+        if (has) {
+            float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)li * kInstRecDw);
+            dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
+            dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
+            dst[2] = make_float4(x.MV[2][2], x.tv[0], x.tv[1], x.tv[2]);
+            dst[3] = make_float4(x.qo[0], x.qo[1], x.qo[2], x.det);
+            dst[4] = make_float4(x.sc[0], x.sc[1], x.sc[2], __int_as_float(obj));
+            dst[5] = make_float4(__uint_as_float(kBase), o0.x, o0.y, o0.z);
+            rects[li] = make_float4(r.x0, r.x1, r.y0, r.y1);
+        }
+    }
+}
+
 // IDS: 0 = no id tensor, 1 = visibility ids (world-local triangle index),
 // 2 = segmask (objectID of the winner's instance)
 // CLS: exact per-strip classification of the listed large triangles (64x64 tiles only)
-template <int IDS, bool TEX, int TW, int TH, bool CLS = false>
+// MULTI: groups of one-tile views whose worlds fit one TLAS pass (p.bvhGroupViews > 1; 64x64 tiles only).  A
+// workgroup renders p.bvhGroupViews consecutive VIEWS: their TLASes are built side by side, by different waves,
+// in one phase I -- a phase most waves of a workgroup sit out (one wave's worth of instances) and whose length
+// is the latency of its pose loads, not their number -- then one tile after the other.  A separate
+// instantiation: it has no pass loop (fewer scalar registers live through the traversal), and the plain
+// kernel has none to spare for the group's state (482-triangle worlds, one view per workgroup: 25.4 us
+// without it, 26.5 us with the state compiled in).
+template <int IDS, bool TEX, int TW, int TH, bool CLS = false, bool MULTI = false>
 __global__ __launch_bounds__(kWave *(TH / 8), 4)
 void bvhTileKernel(const RasterParams p)
 {
@@ -439,11 +504,14 @@ void bvhTileKernel(const RasterParams p)
     // over ONE build of the world's TLAS (worlds that fit a single TLAS pass; the launcher gives
     // one tile per workgroup otherwise): the instance transforms, their screen rectangles and
     // the view constants are per view, not per tile.
-    const uint32_t groupTiles = p.bvhGroupTiles;
+    // (MULTI: one-tile views, workgroup b renders views b groupViews, b groupViews + 1, ...)
+    const uint32_t groupTiles = MULTI ? 1u : p.bvhGroupTiles;
+    const uint32_t groupViews = MULTI ? p.bvhGroupViews : 1u;
     const uint32_t groupsPerView = (tilesPerView + groupTiles - 1) / groupTiles;
-    const uint32_t view = item / groupsPerView;
-    uint32_t tile = (item - view * groupsPerView) * groupTiles;
-    const uint32_t lastTile = min(tile + groupTiles, tilesPerView);
+    uint32_t view = MULTI ? blockIdx.x * groupViews : item / groupsPerView;
+    uint32_t tile = MULTI ? 0u : (item - view * groupsPerView) * groupTiles;
+    // tiles this workgroup has left to render
+    uint32_t left = MULTI ? min(groupViews, p.numViews - view) : min(groupTiles, tilesPerView - tile);
     uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
     const uint32_t passInst = p.bvhPassInst;
     const uint32_t dskip = MRX_BVH_DIAG ? p.debugSkip : 0u;
@@ -469,30 +537,32 @@ void bvhTileKernel(const RasterParams p)
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [16]: counters, [8..10] light direction
     float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 16);                  // [kBigCap] planes, key, box
     WaveScratch *ws = reinterpret_cast<WaveScratch *>(bigList + kBigCap) + wave;      // (fixed offsets first)
-    float *instRec = reinterpret_cast<float *>(ws - wave + kBvhWaves);                  // [passInst][24]
-    float4 *instRect = reinterpret_cast<float4 *>(instRec + (size_t)passInst * kInstRecDw);
+    // the TLAS of a view: the light direction in the view's frame and the number of instances (four
+    // dwords), [passInst][24] records, [passInst] rectangles; p.bvhGroupViews of them
+    // (every address below is the current view's block + a multiple of passInst: one loop-carried scalar)
+    float *instRec = reinterpret_cast<float *>(ws - wave + kBvhWaves) + 4;
+#define MRX_TLAS_DW (passInst * (kInstRecDw + 4u) + 4u)
+#define MRX_INST_RECT(rec) reinterpret_cast<float4 *>((rec) + (size_t)passInst * kInstRecDw)
+#define MRX_TLAS_HDR(rec) ((rec) - 4)
 
     // ---- view constants (wave-uniform).  Two placements, picked by what measured faster:
-    //      the untextured instantiations work them out in every wave, here; the textured
-    //      ones (which spill) only in the waves that transform instances, inside the pass
-    //      loop, with the light direction handed to the set-up of all waves through LDS.
-    constexpr bool kLvInLds = TEX;
+    //      the plain untextured instantiations work them out in every wave, here; the others
+    //      only in the waves that transform instances, inside the pass loop, with the light
+    //      direction handed to the set-up of all waves through LDS.
+    constexpr bool kLvInLds = TEX || MULTI;
     ViewConst vcAll = {};
     if (!kLvInLds)
         loadViewConst(p, view, vcAll);
-    // (uniform worlds: arithmetic instead of two dependent loads)
-    uint32_t i0, i1;
-    if (p.bvhUniInst) {
-        uint32_t world = view;
-        if (p.bvhUniCams != 1)
-            world = view / p.bvhUniCams;
-        i0 = world * p.bvhUniInst;
-        i1 = i0 + p.bvhUniInst;
-    } else {
-        const uint32_t world = p.viewWorld[view];
-        i0 = p.worldInstStart[world];
-        i1 = p.worldInstStart[world + 1];
-    }
+    // ---- which TLAS this wave helps to build in phase I: wave w works on view w % groupViews of the
+    //      group (groupViews is a power of two), chunks w / groupViews, + 8 / groupViews, ... of its
+    //      instances; the instance rows of that view (none: a view past the end of the group)
+    const uint32_t vShift = MULTI ? (uint32_t)__builtin_ctz(groupViews) : 0u;
+    const uint32_t tI = (uint32_t)wave & (groupViews - 1u), ch0 = (uint32_t)wave >> vShift;
+    const uint32_t chStride = (uint32_t)kBvhWaves >> vShift;
+    const uint32_t myView = view + tI;
+    uint32_t i0 = 0, i1 = 0;
+    if (tI < left)
+        viewInstances(p, myView, i0, i1);
     const float isx = __builtin_amdgcn_rcpf(p.sx), isz = __builtin_amdgcn_rcpf(p.sz);
     const float invNear = p.invNear, invFar = p.invFar;
     float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
@@ -502,8 +572,10 @@ void bvhTileKernel(const RasterParams p)
     {
         // the waves that have instances to transform in the first pass go straight to their
         // pose loads: the others clear the depth buffer for them
-        const uint32_t n0 = i1 > i0 ? min(passInst, i1 - i0) : 0u;
-        const uint32_t busy = min((n0 + kWave - 1u) / kWave, (uint32_t)kBvhWaves);
+        // (groups of views: the waves that may have instances to transform, by the largest world)
+        const uint32_t n0 = MULTI ? (p.bvhUniInst ? min(passInst, p.bvhUniInst) : passInst)
+                                  : (i1 > i0 ? min(passInst, i1 - i0) : 0u);
+        const uint32_t busy = min(((n0 + kWave - 1u) / kWave) << vShift, (uint32_t)kBvhWaves);
         if (busy >= (uint32_t)kBvhWaves) {
             for (int i = threadIdx.x; i < TW * TH; i += kWave * kBvhWaves)
                 zbuf[i] = packHit(invFar, 0u);
@@ -528,7 +600,9 @@ void bvhTileKernel(const RasterParams p)
     uint32_t par = 0;
     uint32_t passBase = i0;
     do {                                              // (an empty world: one pass over no instances)
-        const uint32_t n = i1 > passBase ? min(passInst, i1 - passBase) : 0u;
+        // (groups of views: one pass, nI the instances of the view whose TLAS this wave works on)
+        const uint32_t nI = i1 > passBase ? min(passInst, i1 - passBase) : 0u;
+        uint32_t n = nI;
         const bool lastPass = passBase + passInst >= i1;
         if (passBase != i0) {
             // (the first pass has nothing to wait for: the barrier that closes phase I also
@@ -548,47 +622,28 @@ void bvhTileKernel(const RasterParams p)
         //      64^2 ... 256^2 views, 482 ... 4994 triangles: the sphere wins by 3-5 % everywhere.)
         //      The object's range, root and box were copied per instance at load: no load
         //      depends on another here (an instance whose object id is negative this step is hidden).
-        //      (textured instantiations: only the waves that have instances to transform work
-        //      out the view constants; wave 0 always does, and leaves the light direction in LDS)
+        //      (only the waves that have instances to transform work out the view constants; the wave
+        //      with the view's first chunk always does, and leaves the light direction in LDS)
         ViewConst vc = vcAll;
-        if (kLvInLds && (uint32_t)wave * kWave < n) {
-            loadViewConst(p, view, vc);
-            if (threadIdx.x == 0) {
-                ctrl[8] = __float_as_uint(vc.lv[0]);
-                ctrl[9] = __float_as_uint(vc.lv[1]);
-                ctrl[10] = __float_as_uint(vc.lv[2]);
-            }
-        }
-        for (uint32_t ch = (uint32_t)wave; ch * kWave < n; ch += kBvhWaves) {
-            const uint32_t li = ch * kWave + (uint32_t)lane;
-            const bool has = li < n;
-            const uint32_t row = passBase + (has ? li : 0u);
-            const int32_t obj = p.instObj[row];
-            const float4 *oi = reinterpret_cast<const float4 *>(p.instInfo + row);
-            const float4 o0 = oi[0], omin = oi[1], omax = oi[2];
-            const uint32_t kBase = p.instKBase[row];
-            InstXform x;
-            instanceTransform(p, vc, row, x);
-            Rect r = sphereRect(p, x, omin, omax, isx, isz);
-            if (!(obj >= 0) || __float_as_uint(o0.y) == 0u) {    // nothing to draw: a rectangle nothing meets
-                r.x0 = r.y0 = __builtin_inff();
-                r.x1 = r.y1 = -__builtin_inff();
-            }
-            if (has) {
-                float4 *dst = reinterpret_cast<float4 *>(instRec + (size_t)li * kInstRecDw);
-                dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
-                dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
-                dst[2] = make_float4(x.MV[2][2], x.tv[0], x.tv[1], x.tv[2]);
-                dst[3] = make_float4(x.qo[0], x.qo[1], x.qo[2], x.det);
-                dst[4] = make_float4(x.sc[0], x.sc[1], x.sc[2], __int_as_float(obj));
-                dst[5] = make_float4(__uint_as_float(kBase), o0.x, o0.y, o0.z);
-                instRect[li] = make_float4(r.x0, r.x1, r.y0, r.y1);
-            }
+        float *const myRec = instRec + (size_t)tI * MRX_TLAS_DW;
+        if (kLvInLds && ch0 * kWave < nI)
+            loadViewConst(p, myView, vc);
+        tlasChunks(p, vc, passBase, nI, ch0, chStride, myRec, passInst, isx, isz, lane);
+        // (the header after the records: ahead of them its write would wait for the camera loads before the
+        // instance loads are even issued)
+        if (kLvInLds && ch0 == 0 && lane == 0) {
+            if (nI != 0)
+                *reinterpret_cast<float4 *>(MRX_TLAS_HDR(myRec)) =
+                    make_float4(vc.lv[0], vc.lv[1], vc.lv[2], __uint_as_float(nI));
+            else
+                MRX_TLAS_HDR(myRec)[3] = __uint_as_float(0u);   // (no instances: only the count is read)
         }
         __syncthreads();
         MRX_STAMP(1);
 
         for (;;) {                                    // the tiles of the group (one, unless the world fits one pass)
+        if (MULTI)
+            n = rflu(__float_as_uint(MRX_TLAS_HDR(instRec)[3]));   // (the instances of this tile's view)
         // ---- phase II: geometry.  The waves split the work by instance: flat
         //      objects round-robin, the eight children of a BLAS root one per
         //      wave.  All control flow of a wave is wave-uniform.
@@ -677,7 +732,7 @@ void bvhTileKernel(const RasterParams p)
                     } else if (chunk < numChunks) {
                         // next 64 instances of the TLAS: lane = instance
                         const uint32_t li = chunk * kWave + lane;
-                        const float4 ir = instRect[li < n ? li : 0u];
+                        const float4 ir = MRX_INST_RECT(instRec)[li < n ? li : 0u];
                         const float4 oi = *reinterpret_cast<const float4 *>(
                             instRec + (size_t)(li < n ? li : 0u) * kInstRecDw + 20);
                         Rect r;
@@ -730,9 +785,10 @@ void bvhTileKernel(const RasterParams p)
                     kTri = __float_as_uint(a5.x) + (e.y - __float_as_uint(a5.y));
                     // (the light direction comes from LDS batch by batch: held in registers it
                     // costs scalar spills in every loop below)
-                    const float lv[3] = { kLvInLds ? __uint_as_float(ctrl[8]) : vcAll.lv[0],
-                                          kLvInLds ? __uint_as_float(ctrl[9]) : vcAll.lv[1],
-                                          kLvInLds ? __uint_as_float(ctrl[10]) : vcAll.lv[2] };
+                    float4 lv4 = make_float4(vcAll.lv[0], vcAll.lv[1], vcAll.lv[2], 0.0f);
+                    if (kLvInLds)
+                        lv4 = *reinterpret_cast<const float4 *>(MRX_TLAS_HDR(instRec));
+                    const float lv[3] = { lv4.x, lv4.y, lv4.z };
                     // (what the set-up reads of the kernel's parameters, fetched per batch from the
                     // kernel-argument segment instead of living in scalar registers: see ResolveArgs)
                     KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1069,7 +1125,7 @@ void bvhTileKernel(const RasterParams p)
             const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
             resolveStrip<IDS, TEX, TW, TH, true>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
         }
-        if (++tile >= lastTile)
+        if (--left == 0)
             break;
         // ---- the next tile of the group: this wave's strip of the depth buffer is cleared (nobody else
         //      touches it between the barrier ahead of the large pass and the one below), the rectangle
@@ -1077,18 +1133,30 @@ void bvhTileKernel(const RasterParams p)
         //      direction stay.  One barrier: every strip is clear before anyone merges into it.
         for (int i = lane; i < TW * 8; i += kWave)
             zbuf[8 * wave * TW + i] = packHit(invFar, 0u);
-        tileX0 = (tile % tilesFast) * TW;
-        tileY0 = (tile / tilesFast) * TH;
-        TX0 = (float)tileX0; TX1 = (float)(tileX0 + TW - 1);
-        TY0 = (float)tileY0; TY1 = (float)(tileY0 + TH - 1);
+        if (MULTI) {
+            // the next view of the group: its TLAS is the next block
+            ++view;
+            instRec += MRX_TLAS_DW;
+        } else {
+            ++tile;
+            tileX0 = (tile % tilesFast) * TW;
+            tileY0 = (tile / tilesFast) * TH;
+            TX0 = (float)tileX0; TX1 = (float)(tileX0 + TW - 1);
+            TY0 = (float)tileY0; TY1 = (float)(tileY0 + TH - 1);
+        }
         par ^= 4u;
         doneIdx ^= 2u;
         __syncthreads();
         }
+        if (MULTI)
+            break;                                    // (groups of views: every world fits the one pass)
         passBase += passInst;
     } while (passBase < i1);
     MRX_STAMP(6);
 #undef MRX_STAMP
+#undef MRX_TLAS_DW
+#undef MRX_INST_RECT
+#undef MRX_TLAS_HDR
 }
 
 }  // namespace
@@ -1097,15 +1165,18 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex attrMutex;
 // LDS bytes of one workgroup for a tile shape
-size_t ldsFor(uint32_t passInst, bool textured, int tw, int th)
+size_t ldsFor(uint32_t passInst, bool textured, int tw, int th, uint32_t tlasBlocks)
 {
     const size_t cap = (size_t)tabCap(textured, tw, th);
     return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th) * 64 +
-           (size_t)passInst * kInstRecDw * 4 + (size_t)passInst * 16 + sizeof(WaveScratch) * (size_t)(th / 8);
+           ((size_t)passInst * (kInstRecDw + 4) * 4 + 16) * tlasBlocks + sizeof(WaveScratch) * (size_t)(th / 8);
 }
 }  // namespace
 
-size_t bvhLdsBytes(uint32_t passInst, bool textured) { return ldsFor(passInst, textured, 64, 64); }
+size_t bvhLdsBytes(uint32_t passInst, bool textured, uint32_t groupViews)
+{
+    return ldsFor(passInst, textured, 64, 64, groupViews);
+}
 
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
 {
@@ -1117,8 +1188,16 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     const int tw = p.bvhTile == 2 ? 32 : 64, th = p.bvhTile == 0 ? 64 : 32;
     const uint32_t tilesPerView = ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
     const uint32_t groupTiles = std::max<uint32_t>(1u, std::min<uint32_t>(p.bvhGroupTiles, tilesPerView));
-    const uint32_t items = p.numViews * ((tilesPerView + groupTiles - 1) / groupTiles);
-    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th);
+    // groups of views (MULTI): one-tile views, 64x64 tiles, every world in one TLAS pass (the host's
+    // business), a power of two, at most one view per wave
+    const uint32_t groupViews = p.bvhGroupViews;
+    const bool multi = groupViews > 1;
+    if (groupViews == 0 || (groupViews & (groupViews - 1)) != 0 || groupViews > (uint32_t)(th / 8) ||
+        (multi && (tilesPerView != 1 || p.bvhTile != 0)))
+        return hipErrorInvalidValue;
+    const uint32_t items = multi ? (p.numViews + groupViews - 1) / groupViews
+                                 : p.numViews * ((tilesPerView + groupTiles - 1) / groupTiles);
+    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th, groupViews);
     const dim3 grid(items), block(kWave * (th / 8));
     // The kernel needs more dynamic LDS than the 64 KB a launch may ask for by default.  The
     // opt-in is a property of (function, device) -- a renderer per device in one process
@@ -1133,27 +1212,29 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
         if (dev < 0 || dev >= kMaxDevices)
             return hipErrorInvalidDevice;
     }
-#define MRX_BVH(I, T, W, H, C)                                                                 \
+#define MRX_BVH(I, T, W, H, C, M)                                                               \
     do {                                                                                       \
         static size_t allowed[kMaxDevices] = {};                                               \
         {                                                                                      \
             std::lock_guard<std::mutex> guard(attrMutex);                                      \
             if (lds > allowed[dev]) {                                                          \
-                const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H, C>, \
+                const hipError_t e = hipFuncSetAttribute((const void *)bvhTileKernel<I, T, W, H, C, M>, \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (e != hipSuccess)                                                           \
                     return e;                                                                  \
                 allowed[dev] = lds;                                                            \
             }                                                                                  \
         }                                                                                      \
-        bvhTileKernel<I, T, W, H, C><<<grid, block, lds, stream>>>(p);                         \
+        bvhTileKernel<I, T, W, H, C, M><<<grid, block, lds, stream>>>(p);                      \
     } while (0)
 #define MRX_BVH_SHAPE(I, T)                                                                    \
     do {                                                                                       \
-        if (p.bvhTile == 0 && p.bvhClassify) MRX_BVH(I, T, 64, 64, true);                      \
-        else if (p.bvhTile == 0) MRX_BVH(I, T, 64, 64, false);                                 \
-        else if (p.bvhTile == 1) MRX_BVH(I, T, 64, 32, false);                                 \
-        else MRX_BVH(I, T, 32, 32, false);                                                     \
+        if (p.bvhTile == 0 && multi && p.bvhClassify) MRX_BVH(I, T, 64, 64, true, true);       \
+        else if (p.bvhTile == 0 && multi) MRX_BVH(I, T, 64, 64, false, true);                  \
+        else if (p.bvhTile == 0 && p.bvhClassify) MRX_BVH(I, T, 64, 64, true, false);          \
+        else if (p.bvhTile == 0) MRX_BVH(I, T, 64, 64, false, false);                          \
+        else if (p.bvhTile == 1) MRX_BVH(I, T, 64, 32, false, false);                          \
+        else MRX_BVH(I, T, 32, 32, false, false);                                              \
     } while (0)
     if (ids == 2) {
         if (tex) MRX_BVH_SHAPE(2, true); else MRX_BVH_SHAPE(2, false);

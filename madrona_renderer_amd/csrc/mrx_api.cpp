@@ -967,6 +967,30 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_TILES"))
             p.bvhGroupTiles = (uint32_t)std::max(1, std::min((int)tpv, std::atoi(dbg)));
     }
+    // One-tile views whose worlds fit one pass: two views per workgroup, their TLASes built side by side (bvh.hip,
+    // MULTI) -- phase I is as long as the latency of its pose loads whether one wave works in it or two, and the
+    // texel loads at the end of the first view's tile overlap the traversal of the second.  As long as the groups
+    // still fill the chip (two resident workgroups per CU) and two TLASes leave room for two workgroups in a CU's
+    // LDS: worlds of up to 64 instances (profiles/r03_bvh_group_views.txt).
+    p.bvhGroupViews = 1;
+    {
+        const uint32_t tpv = ((nfast + 63u) / 64u) * ((nslow + 63u) / 64u);
+        if (tpv == 1 && p.bvhTile == 0 && maxWorldInst <= p.bvhPassInst) {
+            int cus = 0;
+            MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
+            const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
+            const bool tex = !texDescs.empty();
+            uint32_t v = 1;
+            while (v < 8u && nviews / (2u * v) >= resident && bvhLdsBytes(p.bvhPassInst, tex, 2u * v) <= 80u * 1024u)
+                v *= 2;
+            p.bvhGroupViews = v;
+            if (const char *dbg = std::getenv("MRX_BVH_GROUP_VIEWS")) {
+                const int want = std::atoi(dbg);
+                if (want == 1 || want == 2 || want == 4 || want == 8)
+                    p.bvhGroupViews = (uint32_t)want;
+            }
+        }
+    }
 
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;

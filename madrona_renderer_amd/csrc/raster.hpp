@@ -148,6 +148,9 @@ struct RasterParams {
     // tiles of a view one workgroup renders in turn over one TLAS build (1 when a world needs several
     // TLAS passes; filled in by the host, MRX_BVH_GROUP_TILES overrides)
     uint32_t bvhGroupTiles;
+    // one-tile views a workgroup renders in turn, their TLASes built side by side in one phase I (a power of
+    // two; 1 unless every world fits one TLAS pass; filled in by the host, MRX_BVH_GROUP_VIEWS overrides)
+    uint32_t bvhGroupViews;
 };
 
 // ---- the argument header of the group kernel's fast prologue (raster.hip, FAST) -------------------------------------
@@ -213,6 +216,6 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream);
 constexpr uint32_t kBvhMaxWorldTris = 0x1FFFFEu;   // the depth buffer's key holds 21 bits of triangle index
 // dynamic LDS bytes one workgroup of the BVH kernel needs for `passInst` instance records
-size_t bvhLdsBytes(uint32_t passInst, bool textured);
+size_t bvhLdsBytes(uint32_t passInst, bool textured, uint32_t groupViews);
 
 }  // namespace mrx

@@ -316,11 +316,18 @@ __device__ __forceinline__ uint32_t shadeTextured(const RasterParams &p,
 template <size_t BYTES = sizeof(RasterParams)>
 __device__ __forceinline__ void touchKernelArguments()
 {
-    static_assert(BYTES > 0x180 && BYTES + 32 <= 0x200, "seven or eight lines: adjust the offsets below");
+    static_assert(BYTES > 0x180 && BYTES + 32 <= 0x240, "seven to nine lines: adjust the offsets below");
     const __attribute__((address_space(4))) char *ka =
         (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
-    if (BYTES + 32 > 0x1c0)
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8;
+    if (BYTES + 32 > 0x200)
+        asm volatile("s_load_dword %0, %9, 0x0\n\ts_load_dword %1, %9, 0x40\n\ts_load_dword %2, %9, 0x80\n\t"
+                     "s_load_dword %3, %9, 0xc0\n\ts_load_dword %4, %9, 0x100\n\ts_load_dword %5, %9, 0x140\n\t"
+                     "s_load_dword %6, %9, 0x180\n\ts_load_dword %7, %9, 0x1c0\n\ts_load_dword %8, %9, 0x200\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8)
+                     : "s"(ka));
+    else if (BYTES + 32 > 0x1c0)
         asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
                      "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
                      "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
