@@ -506,13 +506,28 @@ void bvhTileKernel(const RasterParams p)
     // the view constants are per view, not per tile.
     // (MULTI: one-tile views, workgroup b renders views b groupViews, b groupViews + 1, ...)
     const uint32_t groupTiles = MULTI ? 1u : p.bvhGroupTiles;
-    const uint32_t groupViews = MULTI ? p.bvhGroupViews : 1u;
+    const uint32_t groupViews = MULTI ? (p.bvhGroupViews & 0xFFFFu) : 1u;
     const uint32_t groupsPerView = (tilesPerView + groupTiles - 1) / groupTiles;
     uint32_t view = MULTI ? blockIdx.x * groupViews : item / groupsPerView;
     uint32_t tile = MULTI ? 0u : (item - view * groupsPerView) * groupTiles;
     // tiles this workgroup has left to render
     uint32_t left = MULTI ? min(groupViews, p.numViews - view) : min(groupTiles, tilesPerView - tile);
     uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
+    //   Wave priority against the age order (MULTI, launches whose groups all run at once).  A CU holds two of
+    // these workgroups, and its instruction arbiters serve the older wave first: the workgroup dispatched second to a
+    // CU -- index >= the number of CUs: the dispatcher gives every CU one workgroup before any gets its second --
+    // runs in the gaps the first one leaves.  Measured on 512 workgroups of two 482-triangle views each (in-kernel
+    // clock per view, profiles/r03_bvh_priority.txt): workgroups 0..255 take 15.3 us for their two views,
+    // workgroups 256..511 17.9 us -- a step at 256 that follows the index whatever views are dealt where -- and the
+    // launch ends with the slow half.  The younger workgroup therefore runs its first view at wave priority 1 and
+    // its second at 0 (bits 17..19 of p.bvhGroupViews = 2; bits 20..31 = the first young index): 16.5 / 16.9 us,
+    // the launch 24.2 -> 21.8 us.  (1 = priority 1 throughout: the step turns round, 18.0 / 15.3; 3 = and the older
+    // workgroup at priority 1 in its second view: as 2.  Launches of several generations lose with any of them --
+    // every later workgroup would be `young` -- and keep the hardware's order.)
+    const uint32_t prioMode = MULTI ? (p.bvhGroupViews >> 17) & 7u : 0u;
+    const bool young = MULTI && blockIdx.x >= (p.bvhGroupViews >> 20);
+    if (MULTI && prioMode && young)
+        __builtin_amdgcn_s_setprio(1);
     const uint32_t passInst = p.bvhPassInst;
     const uint32_t dskip = MRX_BVH_DIAG ? p.debugSkip : 0u;
     if (dskip & 16u)
@@ -1137,6 +1152,12 @@ void bvhTileKernel(const RasterParams p)
             // the next view of the group: its TLAS is the next block
             ++view;
             instRec += MRX_TLAS_DW;
+            if (prioMode >= 2) {
+                if (young)
+                    __builtin_amdgcn_s_setprio(0);
+                else if (prioMode == 3)
+                    __builtin_amdgcn_s_setprio(1);
+            }
         } else {
             ++tile;
             tileX0 = (tile % tilesFast) * TW;
@@ -1153,6 +1174,9 @@ void bvhTileKernel(const RasterParams p)
         passBase += passInst;
     } while (passBase < i1);
     MRX_STAMP(6);
+    if (MRX_BVH_DIAG && stamps && lane == 0)     // where this wave ran: HW_ID (reg 4) and XCC_ID (reg 20)
+        stamps[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                    (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #undef MRX_STAMP
 #undef MRX_TLAS_DW
 #undef MRX_INST_RECT
@@ -1190,7 +1214,7 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     const uint32_t groupTiles = std::max<uint32_t>(1u, std::min<uint32_t>(p.bvhGroupTiles, tilesPerView));
     // groups of views (MULTI): one-tile views, 64x64 tiles, every world in one TLAS pass (the host's
     // business), a power of two, at most one view per wave
-    const uint32_t groupViews = p.bvhGroupViews;
+    const uint32_t groupViews = p.bvhGroupViews & 0xFFFFu;
     const bool multi = groupViews > 1;
     if (groupViews == 0 || (groupViews & (groupViews - 1)) != 0 || groupViews > (uint32_t)(th / 8) ||
         (multi && (tilesPerView != 1 || p.bvhTile != 0)))

@@ -989,6 +989,15 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
                 if (want == 1 || want == 2 || want == 4 || want == 8)
                     p.bvhGroupViews = (uint32_t)want;
             }
+            // Launches whose groups all run at once: the workgroup dispatched second to a CU runs its first view at
+            // wave priority 1 (bvh.hip: the arbiters serve the older workgroup first, and the launch ends with the
+            // younger half).  MRX_BVH_PRIO: 0 off, 1 / 2 / 3 the modes measured there.
+            int prio = 2;
+            if (const char *dbg = std::getenv("MRX_BVH_PRIO"))
+                prio = std::max(0, std::min(3, std::atoi(dbg)));
+            const uint32_t gv = p.bvhGroupViews;
+            if (gv > 1 && prio && (nviews + gv - 1) / gv <= resident)
+                p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
         }
     }
 

@@ -149,7 +149,8 @@ struct RasterParams {
     // TLAS passes; filled in by the host, MRX_BVH_GROUP_TILES overrides)
     uint32_t bvhGroupTiles;
     // one-tile views a workgroup renders in turn, their TLASes built side by side in one phase I (a power of
-    // two; 1 unless every world fits one TLAS pass; filled in by the host, MRX_BVH_GROUP_VIEWS overrides)
+    // two; 1 unless every world fits one TLAS pass; filled in by the host, MRX_BVH_GROUP_VIEWS overrides);
+    // bits 17..19: wave-priority mode of the younger workgroups (bvh.hip; 0 off), bits 20..31: the first young index
     uint32_t bvhGroupViews;
 };
 

@@ -312,22 +312,23 @@ __device__ __forceinline__ uint32_t shadeTextured(const RasterParams &p,
 // One dword of every line, requested together and waited for once at kernel entry, brings the whole block into
 // the scalar cache up front; the lazy reads then hit.  Measured (profiles/r03_kernarg.txt): headline 22.56 -> 22.14
 // us, 1024 worlds 9.46 -> 9.35, 2048 worlds 13.94 -> 13.60.
-// BYTES = size of the explicit arguments; the hidden ones (grid size ...) follow within the next line or two.
+// BYTES = size of the explicit arguments: only lines that hold some of them are touched (a kernel that uses no hidden
+// argument has none, and a read past the end of the block may leave the pool it was carved from).
 template <size_t BYTES = sizeof(RasterParams)>
 __device__ __forceinline__ void touchKernelArguments()
 {
-    static_assert(BYTES > 0x180 && BYTES + 32 <= 0x240, "seven to nine lines: adjust the offsets below");
+    static_assert(BYTES > 0x180 && BYTES <= 0x240, "seven to nine lines: adjust the offsets below");
     const __attribute__((address_space(4))) char *ka =
         (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8;
-    if (BYTES + 32 > 0x200)
+    if (BYTES > 0x200)
         asm volatile("s_load_dword %0, %9, 0x0\n\ts_load_dword %1, %9, 0x40\n\ts_load_dword %2, %9, 0x80\n\t"
                      "s_load_dword %3, %9, 0xc0\n\ts_load_dword %4, %9, 0x100\n\ts_load_dword %5, %9, 0x140\n\t"
                      "s_load_dword %6, %9, 0x180\n\ts_load_dword %7, %9, 0x1c0\n\ts_load_dword %8, %9, 0x200\n\t"
                      "s_waitcnt lgkmcnt(0)"
                      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8)
                      : "s"(ka));
-    else if (BYTES + 32 > 0x1c0)
+    else if (BYTES > 0x1c0)
         asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
                      "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
                      "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"

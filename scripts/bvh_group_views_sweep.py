@@ -1,5 +1,6 @@
 """One-tile views per workgroup in the BVH kernel (MRX_BVH_GROUP_VIEWS): device us per render under 1, 2, 4
-views per group, and what the host picks by itself (GPU box)."""
+views per group (two: with and without the wave priority of the younger workgroups, MRX_BVH_PRIO), and what the
+host picks by itself (GPU box)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
@@ -16,15 +17,17 @@ cases = [("1024 x 64^2, 40 cubes (482 tris)", scenes.cube_field(1024, 40), 200),
          ("1024 x 32^2, 40 cubes", scenes.cube_field(1024, 40, width=32, height=32), 200)]
 for name, desc, steps in cases:
     row = []
-    for g in ("1", "2", "4", ""):
+    for g in ("1", "2 prio0", "2", "4", ""):
+        for k in ("MRX_BVH_GROUP_VIEWS", "MRX_BVH_PRIO"):
+            os.environ.pop(k, None)
         if g:
-            os.environ["MRX_BVH_GROUP_VIEWS"] = g
-        else:
-            os.environ.pop("MRX_BVH_GROUP_VIEWS", None)
+            os.environ["MRX_BVH_GROUP_VIEWS"] = g.split()[0]
+        if "prio0" in g:
+            os.environ["MRX_BVH_PRIO"] = "0"
         r = scenes.make_renderer(desc)
         t0 = time.time()
         while time.time() - t0 < 0.15:
             r.time_renders(10)
         row.append(min(r.time_renders(steps) for _ in range(3)) / steps * 1000.0)
         del r
-    print("%-40s " % name + "  ".join("%s %7.1f" % (g, v) for g, v in zip(("v=1", "v=2", "v=4", "host"), row)), flush=True)
+    print("%-40s " % name + "  ".join("%s %7.1f" % (g, v) for g, v in zip(("v=1", "v=2 no priority", "v=2", "v=4", "host"), row)), flush=True)

@@ -289,6 +289,21 @@ def test_groups_of_one_tile_views_give_the_same_bytes(native, monkeypatch, views
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prio", [0, 1, 2, 3])
+def test_wave_priority_of_the_younger_workgroups_changes_no_pixel(native, monkeypatch, prio):
+    # launches whose groups of views all run at once give the workgroups dispatched second to a CU wave priority 1
+    # for their first view (bvh.hip; the host picks mode 2 from 1024 views on): every mode, on more groups than
+    # the device has CUs, against the oracle (sampled) and against the raster kernels (all views)
+    monkeypatch.setenv("MRX_BVH_GROUP_VIEWS", "2")
+    monkeypatch.setenv("MRX_BVH_PRIO", str(prio))
+    d = meshes.cube_field(num_worlds=640, cubes=12, textured=prio == 3)
+    r, got, ref = _parity(d, variant=BVH)
+    got3 = fetch(make_product(d, visibility=True, variant=3))
+    for k in ("rgb", "depth", "tri_id"):
+        assert np.array_equal(got[k], got3[k])
+
+
+@pytest.mark.gpu
 def test_bench_shape_1024_worlds_482_triangles(native):
     # the shape VERDICT r1 quotes for the chunked raster kernel (94 us): 1024
     # worlds x 64x64, 40 cubes + plane; sampled views against the oracle, all
