@@ -996,7 +996,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             if (const char *dbg = std::getenv("MRX_BVH_PRIO"))
                 prio = std::max(0, std::min(3, std::atoi(dbg)));
             const uint32_t gv = p.bvhGroupViews;
-            if (gv > 1 && prio && (nviews + gv - 1) / gv <= resident)
+            const uint32_t wgs = (nviews + gv - 1) / gv;
+            if (prio && wgs <= resident && wgs > resident / 2u)
                 p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
         }
     }
