@@ -193,9 +193,12 @@ constexpr uint32_t kStashed = (1u << kSlotBits) - 1u;
 
 // Tile shapes (the LDS tile-size sweep of BASELINE configs[2]): TW x TH pixels per workgroup, one wave per
 // TW x 8 strip, so TH / 8 waves; the depth buffer takes TW * TH * 8 bytes of LDS.
-constexpr int tabCap(bool tex, int tw, int th) { return tex ? 256 : (tw * th >= 4096 ? 1024 : 512); }
+// (64x64 tiles, untextured: 768 records and 64 list entries cost cube fields of up to 4994 triangles nothing against
+// 1024 and 96 -- profiles/r03_bvh_priority.txt -- and leave room for two TLAS blocks of 104 instances beside two
+// workgroups per CU; worlds of BLAS meshes, the CLS instantiations, lose 16 % with them and keep the larger ones)
+constexpr int tabCap(bool tex, int tw, int th, bool cls) { return tex ? 256 : (tw * th >= 4096 ? (cls ? 1024 : 768) : 512); }
 constexpr int tabUsable(int cap) { return cap < (int)kStashed ? cap : (int)kStashed; }   // slot kStashed is the marker
-constexpr int bigCap(int tw, int th) { return tw * th >= 4096 ? 96 : 64; }   // (>= 64: one batch always fits an empty list)
+constexpr int bigCap(int tw, int th, bool cls) { return tw * th >= 4096 && cls ? 96 : 64; }   // (>= 64: one batch always fits an empty list)
 
 struct WaveScratch {
     // (instance of the pass, object triangle)
@@ -483,10 +486,10 @@ void bvhTileKernel(const RasterParams p)
     // loads and a barrier either way, and the seven dwords cost the untextured instantiation three VGPRs)
     constexpr int kBvhWaves = TH / 8;             // one wave per TW x 8 strip of the tile
     constexpr int kHalves = TW / 32;              // 32-pixel halves of a strip: 4 pixels of a lane each
-    constexpr int kCap = tabCap(TEX, TW, TH);
+    constexpr int kCap = tabCap(TEX, TW, TH, CLS);
     constexpr uint32_t kUsable = (uint32_t)tabUsable(kCap);      // records a round can hold
     constexpr bool kPartial = TEX || CLS;
-    constexpr int kBigCap = bigCap(TW, TH);
+    constexpr int kBigCap = bigCap(TW, TH, CLS);
     static_assert((TW == 64 || TW == 32) && (TH == 64 || TH == 32), "tile shapes of the sweep");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
@@ -1199,17 +1202,17 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex attrMutex;
 // LDS bytes of one workgroup for a tile shape
-size_t ldsFor(uint32_t passInst, bool textured, int tw, int th, uint32_t tlasBlocks)
+size_t ldsFor(uint32_t passInst, bool textured, int tw, int th, bool cls, uint32_t tlasBlocks)
 {
-    const size_t cap = (size_t)tabCap(textured, tw, th);
-    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th) * 64 +
+    const size_t cap = (size_t)tabCap(textured, tw, th, cls);
+    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th, cls) * 64 +
            ((size_t)passInst * (kInstRecDw + 4) * 4 + 16) * tlasBlocks + sizeof(WaveScratch) * (size_t)(th / 8);
 }
 }  // namespace
 
-size_t bvhLdsBytes(uint32_t passInst, bool textured, uint32_t groupViews)
+size_t bvhLdsBytes(uint32_t passInst, bool textured, bool classify, uint32_t groupViews)
 {
-    return ldsFor(passInst, textured, 64, 64, groupViews);
+    return ldsFor(passInst, textured, 64, 64, classify, groupViews);
 }
 
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
@@ -1231,7 +1234,7 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
         return hipErrorInvalidValue;
     const uint32_t items = multi ? (p.numViews + groupViews - 1) / groupViews
                                  : p.numViews * ((tilesPerView + groupTiles - 1) / groupTiles);
-    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th, groupViews);
+    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th, p.bvhTile == 0 && p.bvhClassify, groupViews);
     const dim3 grid(items), block(kWave * (th / 8));
     // The kernel needs more dynamic LDS than the 64 KB a launch may ask for by default.  The
     // opt-in is a property of (function, device) -- a renderer per device in one process

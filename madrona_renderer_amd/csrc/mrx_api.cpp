@@ -403,6 +403,48 @@ void shellOrientation(const mrx::ObjTri *tris, uint32_t n, mrx::TriMat *mats)
     }
 }
 
+// One-tile views whose worlds fit one pass: two views per workgroup, their TLASes built side by side (bvh.hip,
+// MULTI) -- phase I is as long as the latency of its pose loads whether one wave works in it or two, and the
+// texel loads at the end of the first view's tile overlap the traversal of the second.  As long as the groups
+// still fill the chip (two resident workgroups per CU) and two TLASes leave room for two workgroups in a CU's
+// LDS: untextured worlds of up to 104 instances, textured ones of up to 64 (profiles/r03_bvh_group_views.txt).
+// Called whenever the bound geometry changes (textured or not decides the kernel's tables).
+int chooseBvhGroups(mrx_renderer &r)
+{
+    using namespace mrx;
+    RasterParams &p = r.params;
+    const uint32_t nviews = p.numViews, maxWorldInst = r.info.max_world_instances;
+    p.bvhGroupViews = 1;
+    const uint32_t tpv = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
+    if (tpv == 1 && p.bvhTile == 0 && maxWorldInst <= p.bvhPassInst) {
+        int cus = 0;
+        MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
+        const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
+        const bool tex = p.anyTextured != 0;
+        uint32_t v = 1;
+        while (v < 8u && nviews / (2u * v) >= resident &&
+               bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u * v) <= 80u * 1024u)
+            v *= 2;
+        p.bvhGroupViews = v;
+        if (const char *dbg = std::getenv("MRX_BVH_GROUP_VIEWS")) {
+            const int want = std::atoi(dbg);
+            if (want == 1 || want == 2 || want == 4 || want == 8)
+                p.bvhGroupViews = (uint32_t)want;
+        }
+        // Launches whose groups all run at once: the workgroup dispatched second to a CU runs its first view at
+        // wave priority 1 (bvh.hip: the arbiters serve the older workgroup first, and the launch ends with the
+        // younger half).  MRX_BVH_PRIO: 0 off, 1 / 2 / 3 the modes measured there.
+        int prio = 2;
+        if (const char *dbg = std::getenv("MRX_BVH_PRIO"))
+            prio = std::max(0, std::min(3, std::atoi(dbg)));
+        const uint32_t gv = p.bvhGroupViews;
+        const uint32_t wgs = (nviews + gv - 1) / gv;
+        if (prio && wgs <= resident && wgs > resident / 2u)
+            p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
+    }
+    return MRX_OK;
+}
+
 // Everything that follows from which object each instance row is bound to (r.boundObj):
 // the world-local triangle numbering, the per-view draw lists of the raster kernels, the
 // per-instance BLAS records of the BVH path, which kernel renders, the uniform-world fast
@@ -517,7 +559,7 @@ int bindGeometry(mrx_renderer &r)
     }
     r.info.max_world_triangles = maxWorldTris;
     r.info.render_path = r.useBvh ? 1 : 0;
-    return MRX_OK;
+    return chooseBvhGroups(r);
 }
 
 int buildScene(const mrx_config &cfg, mrx_renderer &r)
@@ -934,7 +976,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.viewWorld = r.viewWorld.ptr;
     // TLAS records of up to 128 instances stay in LDS at once (two workgroups
     // per CU); larger worlds take several passes
-    p.bvhPassInst = std::min<uint32_t>(128u, std::max<uint32_t>(64u, (maxWorldInst + 63u) / 64u * 64u));
+    // (as many as the largest world has, in eights: what the records do not take leaves room for a second TLAS block)
+    p.bvhPassInst = std::min<uint32_t>(128u, std::max<uint32_t>(8u, (maxWorldInst + 7u) / 8u * 8u));
     p.bvhTile = 0;
     if (const char *dbg = std::getenv("MRX_BVH_TILE"))
         p.bvhTile = std::max(0, std::min(2, std::atoi(dbg)));
@@ -950,7 +993,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     if (const char *dbg = std::getenv("MRX_BVH_SMALL_AREA"))
         p.bvhSmallArea = std::max(0, std::min(4096, std::atoi(dbg)));
     if (const char *dbg = std::getenv("MRX_BVH_PASS_INST"))
-        p.bvhPassInst = std::min<uint32_t>(512u, std::max<uint32_t>(64u, (uint32_t)std::atoi(dbg) / 64u * 64u));
+        p.bvhPassInst = std::min<uint32_t>(512u, std::max<uint32_t>(8u, (uint32_t)std::atoi(dbg) / 8u * 8u));
     // Views of several tiles whose world fits one TLAS pass: a workgroup renders a run of the view's
     // tiles over one TLAS build (bvh.hip).  As long a run as leaves one full generation of resident
     // workgroups (two per CU: 512) -- measured, profiles/r03_bvh_group_tiles.txt: 512 views of 256x256
@@ -967,41 +1010,6 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_TILES"))
             p.bvhGroupTiles = (uint32_t)std::max(1, std::min((int)tpv, std::atoi(dbg)));
     }
-    // One-tile views whose worlds fit one pass: two views per workgroup, their TLASes built side by side (bvh.hip,
-    // MULTI) -- phase I is as long as the latency of its pose loads whether one wave works in it or two, and the
-    // texel loads at the end of the first view's tile overlap the traversal of the second.  As long as the groups
-    // still fill the chip (two resident workgroups per CU) and two TLASes leave room for two workgroups in a CU's
-    // LDS: worlds of up to 64 instances (profiles/r03_bvh_group_views.txt).
-    p.bvhGroupViews = 1;
-    {
-        const uint32_t tpv = ((nfast + 63u) / 64u) * ((nslow + 63u) / 64u);
-        if (tpv == 1 && p.bvhTile == 0 && maxWorldInst <= p.bvhPassInst) {
-            int cus = 0;
-            MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
-            const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
-            const bool tex = !texDescs.empty();
-            uint32_t v = 1;
-            while (v < 8u && nviews / (2u * v) >= resident && bvhLdsBytes(p.bvhPassInst, tex, 2u * v) <= 80u * 1024u)
-                v *= 2;
-            p.bvhGroupViews = v;
-            if (const char *dbg = std::getenv("MRX_BVH_GROUP_VIEWS")) {
-                const int want = std::atoi(dbg);
-                if (want == 1 || want == 2 || want == 4 || want == 8)
-                    p.bvhGroupViews = (uint32_t)want;
-            }
-            // Launches whose groups all run at once: the workgroup dispatched second to a CU runs its first view at
-            // wave priority 1 (bvh.hip: the arbiters serve the older workgroup first, and the launch ends with the
-            // younger half).  MRX_BVH_PRIO: 0 off, 1 / 2 / 3 the modes measured there.
-            int prio = 2;
-            if (const char *dbg = std::getenv("MRX_BVH_PRIO"))
-                prio = std::max(0, std::min(3, std::atoi(dbg)));
-            const uint32_t gv = p.bvhGroupViews;
-            const uint32_t wgs = (nviews + gv - 1) / gv;
-            if (prio && wgs <= resident && wgs > resident / 2u)
-                p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
-        }
-    }
-
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;
     inf.num_views = nviews;

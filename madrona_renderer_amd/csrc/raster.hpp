@@ -141,7 +141,7 @@ struct RasterParams {
     const uint32_t *worldInstStart;  // [worlds + 1]
     const uint32_t *viewWorld;       // [views]
     const uint32_t *instKBase;       // [I]
-    uint32_t bvhPassInst;            // instances whose TLAS records fit LDS at once (multiple of 64)
+    uint32_t bvhPassInst;            // instances whose TLAS records fit LDS at once (a multiple of 8)
     int32_t bvhTile;                 // tile of a workgroup: 0 = 64x64, 1 = 64 wide x 32, 2 = 32x32 (MRX_BVH_TILE)
     int32_t bvhSmallArea;            // boxes of up to this many pixels are walked by their triangle's lane
     int32_t bvhClassify;             // 64x64 tiles: the instantiation that classifies listed triangles per strip
@@ -217,6 +217,6 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream);
 constexpr uint32_t kBvhMaxWorldTris = 0x1FFFFEu;   // the depth buffer's key holds 21 bits of triangle index
 // dynamic LDS bytes one workgroup of the BVH kernel needs for `passInst` instance records
-size_t bvhLdsBytes(uint32_t passInst, bool textured, uint32_t groupViews);
+size_t bvhLdsBytes(uint32_t passInst, bool textured, bool classify, uint32_t groupViews);
 
 }  // namespace mrx

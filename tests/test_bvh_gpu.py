@@ -263,7 +263,7 @@ def test_tlas_passes_of_every_size_give_the_same_bytes(native, monkeypatch, pass
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("views_per_group", [1, 2, 4, 8])
-@pytest.mark.parametrize("case", ["cubes-7-worlds", "textured-rt", "small-views", "ragged-two-cameras", "meshes", "hidden"])
+@pytest.mark.parametrize("case", ["cubes-7-worlds", "cubes-101-instances", "textured-rt", "small-views", "ragged-two-cameras", "meshes", "hidden"])
 def test_groups_of_one_tile_views_give_the_same_bytes(native, monkeypatch, views_per_group, case):
     # one-tile views whose worlds fit one TLAS pass: a workgroup renders `views_per_group` consecutive views, their
     # TLASes built side by side by different waves (bvh.hip, MULTI; the host picks 2 from 1024 views on).  View
@@ -271,6 +271,9 @@ def test_groups_of_one_tile_views_give_the_same_bytes(native, monkeypatch, views
     monkeypatch.setenv("MRX_BVH_GROUP_VIEWS", str(views_per_group))
     if case == "cubes-7-worlds":
         d = meshes.cube_field(num_worlds=7, cubes=40)
+    elif case == "cubes-101-instances":
+        # (TLAS blocks of 104 records: what the host gives two views per workgroup at 1024 views and more)
+        d = meshes.cube_field(num_worlds=5, cubes=100)
     elif case == "textured-rt":
         d = meshes.cube_field(num_worlds=5, cubes=30, width=64, height=64, mode="Raytracer", textured=True)
     elif case == "small-views":
