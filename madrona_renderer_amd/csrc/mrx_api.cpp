@@ -421,11 +421,11 @@ int chooseBvhGroups(mrx_renderer &r)
         MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
         const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
         const bool tex = p.anyTextured != 0;
-        uint32_t v = 1;
-        while (v < 8u && nviews / (2u * v) >= resident &&
-               bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u * v) <= 80u * 1024u)
-            v *= 2;
-        p.bvhGroupViews = v;
+        // (by view count, profiles/r03_bvh_group_views.txt: two views per workgroup win where the pairs fit the chip at
+        // once and fill at least three quarters of it -- 768 ... 1024 views on 256 CUs -- and again from four
+        // generations of single views on; in between, two generations of single views beat one and a bit of pairs)
+        const bool pairsPay = ((nviews + 1u) / 2u <= resident && 2u * nviews >= 3u * resident) || nviews >= 4u * resident;
+        p.bvhGroupViews = pairsPay && bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u) <= 80u * 1024u ? 2u : 1u;
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_VIEWS")) {
             const int want = std::atoi(dbg);
             if (want == 1 || want == 2 || want == 4 || want == 8)
