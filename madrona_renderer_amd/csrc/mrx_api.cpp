@@ -415,11 +415,11 @@ int chooseBvhGroups(mrx_renderer &r)
     RasterParams &p = r.params;
     const uint32_t nviews = p.numViews, maxWorldInst = r.info.max_world_instances;
     p.bvhGroupViews = 1;
+    int cus = 0;
+    MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
+    const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
     const uint32_t tpv = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
     if (tpv == 1 && p.bvhTile == 0 && maxWorldInst <= p.bvhPassInst) {
-        int cus = 0;
-        MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
-        const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
         const bool tex = p.anyTextured != 0;
         // (by view count, profiles/r03_bvh_group_views.txt: two views per workgroup win where the pairs fit the chip at
         // once and fill at least three quarters of it -- 768 ... 1024 views on 256 CUs -- and again from four
@@ -431,17 +431,23 @@ int chooseBvhGroups(mrx_renderer &r)
             if (want == 1 || want == 2 || want == 4 || want == 8)
                 p.bvhGroupViews = (uint32_t)want;
         }
-        // Launches whose groups all run at once: the workgroup dispatched second to a CU runs its first view at
-        // wave priority 1 (bvh.hip: the arbiters serve the older workgroup first, and the launch ends with the
-        // younger half).  MRX_BVH_PRIO: 0 off, 1 / 2 / 3 the modes measured there.
-        int prio = 2;
-        if (const char *dbg = std::getenv("MRX_BVH_PRIO"))
-            prio = std::max(0, std::min(3, std::atoi(dbg)));
-        const uint32_t gv = p.bvhGroupViews;
-        const uint32_t wgs = (nviews + gv - 1) / gv;
-        if (prio && wgs <= resident && wgs > resident / 2u)
-            p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
     }
+    // Launches of one-tile views whose workgroups all run at once (more than one per CU, at most two): the
+    // workgroup dispatched second to a CU runs the first part of its work at wave priority 1 (bvh.hip: the arbiters
+    // serve the older workgroup first, and the launch ends with the younger half).  MRX_BVH_PRIO: 0 off, 1 / 2 / 3
+    // the modes measured there.  (Views of several tiles, one generation of workgroups: 256 x 128^2 gains 4 - 6 %,
+    // 128 x 128^2 of 100 cubes loses 7 %, C5 / 8 loses 1 % -- tiles of a view differ too much in what they hold;
+    // left alone.  profiles/r03_bvh_priority.txt)
+    int prio = 2;
+    if (const char *dbg = std::getenv("MRX_BVH_PRIO"))
+        prio = std::max(0, std::min(3, std::atoi(dbg)));
+    const uint32_t tw = p.bvhTile == 2 ? 32 : 64, th = p.bvhTile == 0 ? 64 : 32;
+    const uint32_t tiles = ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
+    const uint32_t groupTiles = std::max(1u, std::min(p.bvhGroupTiles, tiles));
+    const uint32_t gv = p.bvhGroupViews;
+    const uint32_t wgs = gv > 1 ? (nviews + gv - 1) / gv : nviews * ((tiles + groupTiles - 1) / groupTiles);
+    if (prio && p.bvhTile == 0 && tiles == 1 && wgs <= resident && wgs > resident / 2u)
+        p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
     return MRX_OK;
 }
 
