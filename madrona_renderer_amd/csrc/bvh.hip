@@ -515,6 +515,15 @@ void bvhTileKernel(const RasterParams p)
     uint32_t tile = MULTI ? 0u : (item - view * groupsPerView) * groupTiles;
     // tiles this workgroup has left to render
     uint32_t left = MULTI ? min(groupViews, p.numViews - view) : min(groupTiles, tilesPerView - tile);
+    if (MULTI && groupViews == 2) {
+        // Pairs and single views in one launch: with g workgroups for n views (g <= n <= 2 g) the first n - g
+        // workgroups render two views each, the others one -- all pairs when g = ceil(n / 2); between one and two
+        // views per resident workgroup the host launches as many workgroups as the chip holds, so that 513 ... 1023
+        // views run as one generation (the pairs on the workgroups dispatched first, which the arbiters favour).
+        const uint32_t pairs = p.numViews - gridDim.x;
+        view = blockIdx.x < pairs ? 2u * blockIdx.x : blockIdx.x + pairs;
+        left = blockIdx.x < pairs ? 2u : 1u;
+    }
     uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
     //   Wave priority against the age order (MULTI, launches whose groups all run at once).  A CU holds two of
     // these workgroups, and its instruction arbiters serve the older wave first: the workgroup dispatched second to a
@@ -1016,8 +1025,9 @@ void bvhTileKernel(const RasterParams p)
             if (dskip & 128u) MRX_STAMP(5); else MRX_STAMP(2);
             __syncthreads();
             if (!(dskip & 128u)) MRX_STAMP(3);
-            if (!MULTI) {
-                // (the younger workgroup's priority ends here; read from the argument block: no register held for it)
+            if (!MULTI || left == 1) {
+                // (the priority of a younger workgroup with one view ends here -- of one with two, where it turns to its
+                // second; read from the argument block: no register held for it)
                 KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(pk));
                 if (((pk->bvhGroupViews >> 17) & 7u) >= 2u)
@@ -1232,8 +1242,15 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
     if (groupViews == 0 || (groupViews & (groupViews - 1)) != 0 || groupViews > (uint32_t)(th / 8) ||
         (multi && (tilesPerView != 1 || p.bvhTile != 0)))
         return hipErrorInvalidValue;
-    const uint32_t items = multi ? (p.numViews + groupViews - 1) / groupViews
-                                 : p.numViews * ((tilesPerView + groupTiles - 1) / groupTiles);
+    // (bit 16 with two views per workgroup: as many workgroups as the chip holds -- twice the count in bits 20..31 --
+    // the first numViews - that many with two views, the others with one; bvh.hip)
+    uint32_t items = multi ? (p.numViews + groupViews - 1) / groupViews
+                           : p.numViews * ((tilesPerView + groupTiles - 1) / groupTiles);
+    if (groupViews == 2 && (p.bvhGroupViews & 0x10000u)) {
+        const uint32_t resident = 2u * (p.bvhGroupViews >> 20);
+        if (resident >= items && resident <= p.numViews)
+            items = resident;
+    }
     const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th, p.bvhTile == 0 && p.bvhClassify, groupViews);
     const dim3 grid(items), block(kWave * (th / 8));
     // The kernel needs more dynamic LDS than the 64 KB a launch may ask for by default.  The

@@ -424,12 +424,18 @@ int chooseBvhGroups(mrx_renderer &r)
         // (by view count, profiles/r03_bvh_group_views.txt: two views per workgroup win where the pairs fit the chip at
         // once and fill at least three quarters of it -- 768 ... 1024 views on 256 CUs -- and again from four
         // generations of single views on; in between, two generations of single views beat one and a bit of pairs)
-        const bool pairsPay = ((nviews + 1u) / 2u <= resident && 2u * nviews >= 3u * resident) || nviews >= 4u * resident;
+        // Between one and two views per resident workgroup the launch is as many workgroups as the chip holds, pairs
+        // on the first nviews - resident of them and single views on the others (bit 16; bvh.hip): one generation
+        // for 513 ... 1024 views.
+        const bool mixed = nviews > resident && nviews <= 2u * resident;
+        const bool pairsPay = mixed || nviews >= 4u * resident;
         p.bvhGroupViews = pairsPay && bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u) <= 80u * 1024u ? 2u : 1u;
+        if (p.bvhGroupViews == 2u && mixed && !std::getenv("MRX_BVH_NO_MIXED"))
+            p.bvhGroupViews |= 0x10000u;
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_VIEWS")) {
             const int want = std::atoi(dbg);
             if (want == 1 || want == 2 || want == 4 || want == 8)
-                p.bvhGroupViews = (uint32_t)want;
+                p.bvhGroupViews = (uint32_t)want | (want == 2 ? (p.bvhGroupViews & 0x10000u) : 0u);
         }
     }
     // Launches of one-tile views whose workgroups all run at once (more than one per CU, at most two): the
@@ -444,10 +450,12 @@ int chooseBvhGroups(mrx_renderer &r)
     const uint32_t tw = p.bvhTile == 2 ? 32 : 64, th = p.bvhTile == 0 ? 64 : 32;
     const uint32_t tiles = ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);
     const uint32_t groupTiles = std::max(1u, std::min(p.bvhGroupTiles, tiles));
-    const uint32_t gv = p.bvhGroupViews;
-    const uint32_t wgs = gv > 1 ? (nviews + gv - 1) / gv : nviews * ((tiles + groupTiles - 1) / groupTiles);
+    const uint32_t gv = p.bvhGroupViews & 0xFFFFu;
+    const uint32_t wgs = (p.bvhGroupViews & 0x10000u) ? resident
+                         : gv > 1 ? (nviews + gv - 1) / gv : nviews * ((tiles + groupTiles - 1) / groupTiles);
+    p.bvhGroupViews |= std::min(resident / 2u, 4095u) << 20;      // (the first index of a CU's second workgroup)
     if (prio && p.bvhTile == 0 && tiles == 1 && wgs <= resident && wgs > resident / 2u)
-        p.bvhGroupViews |= (uint32_t)prio << 17 | std::min(resident / 2u, 4095u) << 20;
+        p.bvhGroupViews |= (uint32_t)prio << 17;
     return MRX_OK;
 }
 

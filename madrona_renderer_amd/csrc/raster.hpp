@@ -150,7 +150,9 @@ struct RasterParams {
     uint32_t bvhGroupTiles;
     // one-tile views a workgroup renders in turn, their TLASes built side by side in one phase I (a power of
     // two; 1 unless every world fits one TLAS pass; filled in by the host, MRX_BVH_GROUP_VIEWS overrides);
-    // bits 17..19: wave-priority mode of the younger workgroups (bvh.hip; 0 off), bits 20..31: the first young index
+    // bit 16 (two views): a launch of as many workgroups as the chip holds, pairs on the first of them and single
+    // views on the others; bits 17..19: wave-priority mode of the younger workgroups (bvh.hip; 0 off); bits 20..31:
+    // the index of the first workgroup that is a CU's second (= the number of CUs)
     uint32_t bvhGroupViews;
 };
 
