@@ -26,6 +26,10 @@
 //         over the lanes, large ones go on a shared list every wave rasterises
 //         over its own strip after a barrier; winners are shaded from a table
 //         of records in LDS.
+//   launch  one workgroup per tile, per run of a view's tiles over one TLAS build, or -- one-tile views --
+//         per pair of views whose TLASes two waves build side by side (MULTI); where all workgroups are
+//         resident at once, the one dispatched second to a CU starts at wave priority 1, because the
+//         arbiters serve the older workgroup first (kernel head).
 // A box test only ever skips work: rectangles are padded so that no triangle
 // that could own a pixel is dropped, and the pixel test itself is the spec's.
 // Traversal order is not draw order, so the winner is chosen by (1/depth, then
