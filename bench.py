@@ -21,6 +21,7 @@ ranks with no data-path collective.  Rank 0 prints ONE JSON line:
                            per GPU, render-only and with the RCCL all-gather of
                            the output slabs (sharding.gather_slabs)
   also                     BASELINE configs[1] (1024 worlds), N = 1 only
+  also_bvh                 1024 worlds of 482 triangles through the BVH path, N = 1 only
 
 Other workloads of BASELINE.json are selected with flags (the default is the
 north-star configuration, 4096 worlds x 64x64 cube+plane):
@@ -457,6 +458,23 @@ def run_rank(a):
                        "kernel_us": ms2 * 1000.0 / a.steps,
                        "settle_s": 0.1, "settle_renders": settle2}
         del r2
+
+    if n_gpus == 1 and not a.no_extra and not a.cubes and a.variant == 0:
+        # the BVH ray-trace path on a scene that takes it by itself (more than 128 triangles per world):
+        # 1024 worlds x 64x64, 40 cubes + plane = 482 triangles, against the kernel's own roofline
+        d4 = scenes.cube_field(1024, 40)
+        r4 = scenes.make_renderer(d4, gpu_id=local)
+        settle4 = settle(r4, 0.1)
+        for _ in range(a.warmup):
+            r4.step()
+        w4, ms4 = timed_steps(r4, a.steps, lambda: None)
+        out["also_bvh"] = {"workload": "1024 worlds x 64x64, 40 cubes + plane (482 triangles/world): the BVH path",
+                           "render_path": r4.render_path(),
+                           "value": 1024 * a.steps / w4, "unit": "views/s",
+                           "ms_per_step": w4 * 1000.0 / a.steps, "kernel_us": ms4 * 1000.0 / a.steps,
+                           "roofline": bvh_roofline("1024x64x64+cubes40", ms4 * 1000.0 / a.steps, 1024, 1),
+                           "settle_s": 0.1, "settle_renders": settle4}
+        del r4
 
     if not a.no_strong:
         # BASELINE.json configs[3]: 16384 worlds x 64x64 cube+plane IN TOTAL, world-sharded:

@@ -45,6 +45,10 @@ def test_bench_line_has_the_contract_keys(native):
     st = out["also_strong"]
     assert st["scaling"] == "strong" and st["unit"] == "views/s" and "with_gather" not in st
     assert abs(st["value"] - 2048 / (st["ms_per_step"] * 1e-3)) / st["value"] < 1e-6
+    # the BVH path on a scene that takes it by itself, against its own (VALU-issue) roofline
+    bv = out["also_bvh"]
+    assert bv["render_path"] == "bvh" and bv["unit"] == "views/s" and bv["kernel_us"] > 0
+    assert bv["roofline"]["bound"] == "valu-issue" and 0 < bv["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu
