@@ -45,7 +45,19 @@ def test_bench_line_has_the_contract_keys(native):
     st = out["also_strong"]
     assert st["scaling"] == "strong" and st["unit"] == "views/s" and "with_gather" not in st
     assert abs(st["value"] - 2048 / (st["ms_per_step"] * 1e-3)) / st["value"] < 1e-6
-    # the BVH path on a scene that takes it by itself, against its own (VALU-issue) roofline
+    assert "also" not in out and "also_bvh" not in out           # (--no-extra)
+
+
+@pytest.mark.gpu
+def test_bench_extras_configs1_and_the_bvh_path(native):
+    # without --no-extra the line carries BASELINE configs[1] (`also`) and the BVH path on a scene that takes it by
+    # itself, against its own (VALU-issue) roofline (`also_bvh`)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "10",
+                        "--worlds", "256", "--no-strong", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert out["also"]["unit"] == "views/s" and out["also"]["kernel_us"] > 0
     bv = out["also_bvh"]
     assert bv["render_path"] == "bvh" and bv["unit"] == "views/s" and bv["kernel_us"] > 0
     assert bv["roofline"]["bound"] == "valu-issue" and 0 < bv["roofline"]["frac"] < 1
