@@ -241,6 +241,40 @@ def test_config_c5_4096_worlds_256_textured_raytracer(native, monkeypatch, varia
     assert (ref["segmask"] >= 0).mean() > 0.6
 
 
+@pytest.mark.parametrize("path", ["raster", "bvh"])
+def test_step_can_be_captured_in_a_hip_graph_with_the_pose_update(native, path):
+    # an RL loop that is launch-bound captures "update the poses, render" once and replays it: step() is one
+    # kernel launch on the renderer's stream with nothing that cannot be captured (the first frame, with its
+    # one-time function attributes, was rendered by the constructor).  Three replays of (z += 0.5; step).
+    import torch
+    from tests import meshes as tmeshes
+    d = scenes.synthetic_scene(48) if path == "raster" else tmeshes.cube_field(num_worlds=20, cubes=40)
+    r = make_product(d)
+    assert r.render_path() == path
+    side = torch.cuda.Stream()
+    r.set_stream(side.cuda_stream)
+    pos = r.instance_position_tensor().to_torch()
+    row = 1                                          # (the first cube of world 0 in both scenes)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        r.step()
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            pos[row, 2] += 0.5
+            r.step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    got = fetch(r)
+    inst = list(d.instances)
+    z = np.float32(inst[row][0][2])
+    for _ in range(3):
+        z = np.float32(z + np.float32(0.5))
+    inst[row] = ((inst[row][0][0], inst[row][0][1], float(z)),) + tuple(inst[row][1:])
+    d.instances = inst
+    assert_parity(got, render_oracle(d))
+
+
 @pytest.mark.parametrize("own_stream", [False, True], ids=["null-stream", "torch-side-stream"])
 def test_pose_tensors_are_live_and_stepping_rerenders(native, own_stream):
     # scripts/test.py:137-151: mutate instance_position_tensor in place, step --
