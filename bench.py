@@ -22,6 +22,7 @@ ranks with no data-path collective.  Rank 0 prints ONE JSON line:
                            the output slabs (sharding.gather_slabs)
   also                     BASELINE configs[1] (1024 worlds), N = 1 only
   also_bvh                 1024 worlds of 482 triangles through the BVH path, N = 1 only
+  also_loop                the headline batch with a pose update ahead of every render, N = 1 only
 
 Other workloads of BASELINE.json are selected with flags (the default is the
 north-star configuration, 4096 worlds x 64x64 cube+plane):
@@ -442,6 +443,33 @@ def run_rank(a):
 
     if a.gather and dist is not None:
         out["with_gather"] = gather_leg(r, min(a.steps, 500), total_views)
+    if n_gpus == 1 and not a.no_extra:
+        # The same batch as a simulation loop would drive it: a pose update on the stream ahead of every render
+        # (torch add_ on the instance positions, the tensor the reference's scripts/test.py writes), K iterations;
+        # the update alone for comparison.  Back-to-back renders are the best case for clocks and caches: this is
+        # the other one.
+        import torch
+        pos = r.instance_position_tensor().to_torch()
+        delta = torch.zeros_like(pos)
+        k5 = min(a.steps, 2000)
+        for _ in range(20):
+            pos.add_(delta)
+            r.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k5):
+            pos.add_(delta)
+            r.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k5):
+            pos.add_(delta)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out["also_loop"] = {"workload": "the batch above, a pose update (torch add_ on the instance positions) ahead of every render",
+                            "iterations": k5, "ms_per_iteration": (t1 - t0) * 1000.0 / k5,
+                            "ms_update_alone": (t2 - t1) * 1000.0 / k5,
+                            "ms_per_step_back_to_back": wall * 1000.0 / a.steps}
     del r
 
     if n_gpus == 1 and not a.no_extra and a.worlds != 1024:

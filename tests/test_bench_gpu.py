@@ -61,6 +61,8 @@ def test_bench_extras_configs1_and_the_bvh_path(native):
     bv = out["also_bvh"]
     assert bv["render_path"] == "bvh" and bv["unit"] == "views/s" and bv["kernel_us"] > 0
     assert bv["roofline"]["bound"] == "valu-issue" and 0 < bv["roofline"]["frac"] < 1
+    lp = out["also_loop"]
+    assert lp["ms_per_iteration"] > lp["ms_update_alone"] > 0 and lp["iterations"] == 100
 
 
 @pytest.mark.gpu
