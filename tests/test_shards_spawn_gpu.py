@@ -197,7 +197,7 @@ def test_spawn_crosses_the_kernel_threshold(native):
     # binding enough triangles moves a renderer from the raster group kernel to the BVH path
     import torch
     from oracle import oracle
-    d = meshes.cube_field(num_worlds=3, cubes=8)          # 98 triangles: group kernel
+    d = meshes.cube_field(num_worlds=3, cubes=4)          # 50 triangles: group kernel (small batches cross at 65)
     d.max_instances_per_world = 20
     r = make_product(d, visibility=True)
     fs = oracle.FlatScene(d)
