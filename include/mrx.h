@@ -118,8 +118,9 @@ typedef struct {
     void *stream;               /* hipStream_t to launch on; NULL = null stream */
     uint32_t flags;             /* MRX_FLAG_* */
     int32_t kernel_variant;     /* 0 = default (raster kernels up to 128 triangles per
-                                 * world, BVH path from 129 -- from 65 / 91 for batches of up
-                                 * to 640 / 1024 untextured 64x64 views); 1 = brute-force cross-check;
+                                 * world, BVH path from 129 -- from 65 for batches of up to 640
+                                 * 64x64 views, from 91 for up to 1024 untextured ones);
+                                 * 1 = brute-force cross-check;
                                  * 2 = BVH path always; 3 = raster kernels always */
     /* -- ABI 3 (a caller that sets struct_size = MRX_CONFIG_V2_SIZE passes none of these) --
      * Single-process multi-device: with num_devices > 1 the renderer spans device_ids[0 ..

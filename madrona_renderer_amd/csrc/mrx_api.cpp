@@ -495,7 +495,7 @@ int bindGeometry(mrx_renderer &r)
     // profiles/r02_bvh_crossover.txt); it serves both render modes.
     // MRX_BVH_MIN_TRIS moves the threshold; kernel_variant 2 / 3 force the BVH /
     // the raster kernels.
-    //   Small batches of untextured one-tile views cross over earlier: up to two workgroups per CU the BVH kernel's
+    //   Small batches of one-tile views cross over earlier: up to two workgroups per CU the BVH kernel's
     // launch costs what its slowest workgroup costs, while the raster kernels' 128-slot shape pays for its slots
     // (profiles/r03_bvh_threshold.txt: 512 views of 74 triangles 10.7 against 12.3 us, 1024 views of 98 triangles
     // 18.0 against 18.6; 2048 views and more cross at 122 ... 129).
@@ -508,8 +508,11 @@ int bindGeometry(mrx_renderer &r)
                 break;
             }
         const uint32_t nviews = (uint32_t)viewWorld.size();
-        if (!std::getenv("MRX_BVH_MIN_TRIS") && !anyTex && r.params.nfast <= 64 && r.params.nslow <= 64)
-            minTris = nviews <= 640 ? std::min(minTris, 65u) : nviews <= 1024 ? std::min(minTris, 91u) : minTris;
+        // (textured worlds: the same up to 640 views -- 512 views of 74 triangles 13.0 against 15.5 us -- and at 1024
+        // views only from ~115 triangles on, left at the general threshold)
+        if (!std::getenv("MRX_BVH_MIN_TRIS") && r.params.nfast <= 64 && r.params.nslow <= 64)
+            minTris = nviews <= 640 ? std::min(minTris, 65u)
+                      : nviews <= 1024 && !anyTex ? std::min(minTris, 91u) : minTris;
     }
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= minTris);
     if (r.useBvh && maxWorldTris > kBvhMaxWorldTris)

@@ -199,8 +199,8 @@ struct GroupHeader {
 };
 
 // Default dispatch: worlds of this many triangles and more take the BVH path
-// (measured crossover, profiles/r02_bvh_crossover.txt; MRX_BVH_MIN_TRIS overrides; small batches of untextured
-// 64x64 views cross earlier -- from 65 triangles up to 640 views, from 91 up to 1024: mrx_api.cpp).
+// (measured crossover, profiles/r02_bvh_crossover.txt; MRX_BVH_MIN_TRIS overrides; small batches of 64x64 views
+// cross earlier -- from 65 triangles up to 640 views, from 91 up to 1024 untextured ones: mrx_api.cpp).
 constexpr uint32_t kBvhMinTris = 129;
 
 // Kernel variants (mrx_config.kernel_variant).

@@ -308,8 +308,8 @@ def test_wave_priority_of_the_younger_workgroups_changes_no_pixel(native, monkey
 
 @pytest.mark.gpu
 def test_small_batches_of_untextured_views_cross_over_to_the_bvh_path_earlier(native):
-    # the default dispatch: from 129 triangles per world on, but from 65 for up to 640 untextured 64x64 views and
-    # from 91 for up to 1024 (profiles/r03_bvh_threshold.txt) -- same pixels either way
+    # the default dispatch: from 129 triangles per world on, but from 65 for up to 640 64x64 views and from 91 for
+    # up to 1024 untextured ones (profiles/r03_bvh_threshold.txt) -- same pixels either way
     d = meshes.cube_field(num_worlds=96, cubes=8)                     # 98 triangles
     r, got, ref = _parity(d)
     assert _info(native, r).render_path == 1
@@ -317,7 +317,8 @@ def test_small_batches_of_untextured_views_cross_over_to_the_bvh_path_earlier(na
     for k in ("rgb", "depth", "tri_id"):
         assert np.array_equal(got[k], got3[k])
     assert _info(native, make_product(meshes.cube_field(num_worlds=96, cubes=5))).render_path == 0        # 62 triangles
-    assert _info(native, make_product(meshes.cube_field(num_worlds=96, cubes=8, textured=True))).render_path == 0
+    assert _info(native, make_product(meshes.cube_field(num_worlds=96, cubes=8, textured=True))).render_path == 1
+    assert _info(native, make_product(meshes.cube_field(num_worlds=700, cubes=8, textured=True))).render_path == 0
     assert _info(native, make_product(meshes.cube_field(num_worlds=96, cubes=8, width=128, height=64))).render_path == 0
     assert _info(native, make_product(meshes.cube_field(num_worlds=700, cubes=6))).render_path == 0       # 74 triangles
     assert _info(native, make_product(meshes.cube_field(num_worlds=700, cubes=8))).render_path == 1
