@@ -427,7 +427,10 @@ int chooseBvhGroups(mrx_renderer &r)
         // Between one and two views per resident workgroup the launch is as many workgroups as the chip holds, pairs
         // on the first nviews - resident of them and single views on the others (bit 16; bvh.hip): one generation
         // for 513 ... 1024 views.
-        const bool mixed = nviews > resident && nviews <= 2u * resident;
+        // (worlds of more than 64 instances: only from three quarters of the chip in pairs on -- 576 ... 700 views of
+        // 101-instance worlds lose 4 % to two generations of single views, profiles/r03_bvh_group_views.txt)
+        const bool mixed = nviews > resident && nviews <= 2u * resident &&
+                           (maxWorldInst <= 64u || 2u * nviews >= 3u * resident);
         const bool pairsPay = mixed || nviews >= 4u * resident;
         p.bvhGroupViews = pairsPay && bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u) <= 80u * 1024u ? 2u : 1u;
         if (p.bvhGroupViews == 2u && mixed && !std::getenv("MRX_BVH_NO_MIXED"))
