@@ -113,6 +113,7 @@ public:
     // worlds [shardFirstWorld(i), shardFirstWorld(i + 1)) live on shard i
     uint32_t shardFirstWorld(uint32_t shard) const;
     float timeRenders(int steps);                   // device ms for `steps` renders
+    double timeStepsHost(int steps);                // host us per step() call, `steps` calls back to back
     void mark(int which);                           // HIP event 0/1 on the stream
     float elapsedMs();                              // event1 - event0, waits for 1
     uint64_t bytesPerStep() const;                  // algorithmic HBM bytes / render
@@ -120,6 +121,7 @@ public:
     // output placement as mrx_placement reports it: candidates timed at creation
     int placement(float *candUs, int capacity, float *keptUs) const;
     void setStream(void *hipStream);                // launch on this stream from now on
+    void setShardStream(uint32_t shard, void *hipStream);   // the same for one shard of several
     const char *renderPath() const;                 // "raster" (tiled raster kernels) or "bvh"
 
     uint32_t numAgents;

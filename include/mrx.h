@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MRX_ABI_VERSION 3
+#define MRX_ABI_VERSION 4
 
 enum {
     MRX_OK = 0,
@@ -181,8 +181,10 @@ typedef struct {
     uint32_t bvh_nodes;             /* 8-wide BLAS nodes of all objects     */
     uint32_t bvh_depth;             /* deepest BLAS                         */
     uint32_t max_world_instances;   /* most instances any one world holds   */
+    /* -- ABI 3 (mrx_info writes none of these: see mrx_info_sized) -- */
     uint32_t num_shards;            /* devices the renderer spans (1 unless device_ids) */
 } mrx_info_t;
+#define MRX_INFO_V2_SIZE ((size_t)offsetof(mrx_info_t, num_shards))
 
 /* -- lifetime: replaces Manager::Manager / ~Manager (mgr.cpp:505-527).
  *    Like the reference constructor, mrx_create renders the first frame. */
@@ -233,7 +235,12 @@ int64_t mrx_shard_first_world(mrx_renderer *r, int shard);
  *    `num_shards` over `num_worlds` worlds; shard = num_shards gives num_worlds */
 int64_t mrx_shard_split(uint32_t num_worlds, uint32_t shard, uint32_t num_shards);
 
+/* -- mrx_info writes the first MRX_INFO_V2_SIZE bytes of mrx_info_t -- the struct as ABI 2 declared
+ *    it, whatever the caller was compiled against; mrx_info_sized(r, &info, sizeof info) writes
+ *    min(size, sizeof(mrx_info_t)) bytes, so a caller gets exactly the fields it knows (ABI 4).
+ *    The struct only ever grows at its end. */
 int mrx_info(mrx_renderer *r, mrx_info_t *out);
+int mrx_info_sized(mrx_renderer *r, void *out, size_t size);
 void *mrx_stream(mrx_renderer *r);
 /* -- stream: later launches are enqueued on `stream` (a hipStream_t; NULL = the
  *    device's null stream).  Work already enqueued on the old stream is waited
@@ -247,6 +254,10 @@ int mrx_set_stream(mrx_renderer *r, void *stream);
  *    two HIP events on the renderer's stream; *ms_total = elapsed device ms.
  *    Synchronises the stream before returning. */
 int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total);
+/*    Host side of the same loop: `steps` mrx_step calls back to back with no synchronisation in
+ *    between; *us_per_step = host wall time until the last call returned, per call (what the
+ *    calling thread pays to have one step enqueued on every device).  Synchronises afterwards. */
+int mrx_time_steps_host(mrx_renderer *r, int steps, double *us_per_step);
 /*    mrx_mark(r, 0 | 1) records HIP event 0 / 1 on the renderer's stream;
  *    mrx_elapsed_ms waits for event 1 and returns event1 - event0.  They let a
  *    caller bracket its own timed region of mrx_step calls with device time. */

@@ -183,6 +183,14 @@ float Manager::timeRenders(int steps)
     return ms;
 }
 
+double Manager::timeStepsHost(int steps)
+{
+    double us = 0.0;
+    if (mrx_time_steps_host(impl_->r, steps, &us) != MRX_OK)
+        detail::fatal(mrx_last_error());
+    return us;
+}
+
 void Manager::mark(int which)
 {
     if (mrx_mark(impl_->r, which) != MRX_OK)
@@ -200,7 +208,7 @@ float Manager::elapsedMs()
 uint64_t Manager::bytesPerStep() const
 {
     mrx_info_t info {};
-    if (mrx_info(impl_->r, &info) != MRX_OK)
+    if (mrx_info_sized(impl_->r, &info, sizeof info) != MRX_OK)
         detail::fatal(mrx_last_error());
     return info.bytes_per_step;
 }
@@ -215,7 +223,7 @@ int Manager::placement(float *candUs, int capacity, float *keptUs) const
 const char *Manager::renderPath() const
 {
     mrx_info_t info {};
-    if (mrx_info(impl_->r, &info) != MRX_OK)
+    if (mrx_info_sized(impl_->r, &info, sizeof info) != MRX_OK)
         detail::fatal(mrx_last_error());
     return info.render_path == 1 ? "bvh" : "raster";
 }
@@ -223,6 +231,13 @@ const char *Manager::renderPath() const
 void Manager::setStream(void *hipStream)
 {
     if (mrx_set_stream(impl_->r, hipStream) != MRX_OK)
+        detail::fatal(mrx_last_error());
+}
+
+void Manager::setShardStream(uint32_t shard, void *hipStream)
+{
+    mrx_renderer *sh = mrx_shard(impl_->r, (int)shard);
+    if (!sh || mrx_set_stream(sh, hipStream) != MRX_OK)
         detail::fatal(mrx_last_error());
 }
 

@@ -8,10 +8,18 @@
 #include <cstring>
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <chrono>
+#include <climits>
 #include <map>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
+
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -219,6 +227,9 @@ hipError_t allocOutputs(size_t px, bool wantIds, bool oneAllocation, DevBuf<uint
 
 }  // namespace
 
+struct ShardWorker;
+static void stopShardWorkers(mrx_renderer *r);
+
 struct mrx_renderer {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -268,6 +279,12 @@ struct mrx_renderer {
     // one sub-renderer per device, each owning a contiguous range of the worlds
     std::vector<mrx_renderer *> shards;
     std::vector<uint32_t> shardFirstWorld;      // [shards + 1]
+    // one persistent host thread per device but the first (whose shards the calling thread
+    // launches): mrx_step posts the launch to all of them and returns when every device has its
+    // kernel enqueued -- the host cost of a step is the slowest enqueue, not their sum
+    std::vector<ShardWorker *> workers;
+    std::vector<mrx_renderer *> ownShards;      // (with workers) the shards the calling thread launches
+    uint32_t workerSeq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // what choosePlacement measured (mrx_placement): us per render of every candidate
     // output allocation it timed, in order, and of the one it kept
@@ -293,6 +310,7 @@ struct mrx_renderer {
 
     ~mrx_renderer()
     {
+        stopShardWorkers(this);
         for (mrx_renderer *sh : shards)
             delete sh;
         if (!shards.empty())
@@ -311,6 +329,281 @@ struct mrx_renderer {
         if (ev1) (void)hipEventDestroy(ev1);
     }
 };
+
+
+// ---- shard workers (single-process multi-device) ----------------------------
+// A kernel launch costs the host 3 - 4 us (MI355X_MICROARCH.md), so eight launches issued one
+// after the other from the calling thread cost more than the 13 us a 2048-world shard renders
+// in: the one-Manager form every reference caller uses (/root/reference/scripts/test.py:112-130,
+// one ctor, one step()) would be host-bound at 8 devices.  Each shard but the first therefore
+// has a host thread of its own, created by mrx_create, bound to its device once, parked on a
+// sequence word.  mrx_step stores the next sequence number into every worker's word, launches
+// shard 0 itself and waits until every worker has acknowledged -- when it returns, every
+// device has the kernel in its queue (a caller's next operation on those streams is ordered
+// behind it, exactly as in the serial form), and the host paid for one launch plus a cache-line
+// handshake.  Workers spin on their word for a while after a command (a simulation loop calls
+// step() every few tens of microseconds) and then sleep in a futex; MRX_SHARD_SPIN_US sets how
+// long (default 200), MRX_SHARD_THREADS=0 restores the serial form (startShardWorkers).
+enum : int { kCmdNone = 0, kCmdRender, kCmdSync, kCmdTimed, kCmdExit };
+
+struct ShardWorker {
+    std::vector<mrx_renderer *> shards;         // the shards of ONE device, launched in order
+    std::thread th;
+    // written by the master, read by the worker
+    alignas(64) std::atomic<uint32_t> posted { 0 };
+    int cmd = kCmdNone;
+    int steps = 0;
+    alignas(64) std::atomic<uint32_t> sleeping { 0 };
+    // written by the worker, read by the master
+    alignas(64) std::atomic<uint32_t> done { 0 };
+    int rc = MRX_OK;
+    std::string err;
+    int64_t tSeen = 0, tDone = 0;               // MRX_SHARD_TRACE: when the command was seen / finished
+    alignas(64) std::atomic<uint32_t> masterSleeping { 0 };
+};
+
+namespace {
+
+inline void cpuRelax() { __builtin_ia32_pause(); }
+
+inline long futexWait(std::atomic<uint32_t> *word, uint32_t expected)
+{
+    return syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+
+inline long futexWake(std::atomic<uint32_t> *word)
+{
+    return syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
+int64_t shardSpinNs()
+{
+    static const int64_t ns = [] {
+        const char *e = std::getenv("MRX_SHARD_SPIN_US");
+        return (int64_t)(e ? std::max(0, std::atoi(e)) : 200) * 1000;
+    }();
+    return ns;
+}
+
+bool shardTrace()
+{
+    static const bool on = std::getenv("MRX_SHARD_TRACE") != nullptr;
+    return on;
+}
+
+// MRX_SHARD_TRACE: sums over the render commands of a renderer (ns): post -> worker saw it (worst
+// worker), the worker's launch (worst), the calling thread's own launch, post -> all acknowledged
+struct ShardTrace { int64_t wake = 0, launch = 0, own = 0, total = 0, n = 0; };
+thread_local ShardTrace g_trace;
+
+int64_t nowNs()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// what the shards of one device do for a command, on whichever thread runs it (the shards of a
+// group share a device; it is made current here unless the thread is bound to it for good)
+int groupRun(const std::vector<mrx_renderer *> &shards, int cmd, int steps, bool bindDevice)
+{
+    if (shards.empty())
+        return MRX_OK;
+    if (bindDevice)
+        MRX_HIP(hipSetDevice(shards[0]->device));
+    switch (cmd) {
+    case kCmdRender:
+        for (mrx_renderer *sh : shards)
+            MRX_HIP(sh->launch());
+        return MRX_OK;
+    case kCmdSync:
+        for (mrx_renderer *sh : shards)
+            MRX_HIP(hipStreamSynchronize(sh->stream));
+        return MRX_OK;
+    case kCmdTimed:
+        // every shard's launches between its own two events, the shards of the device interleaved
+        // step by step: the slowest shard's interval spans the device's whole job
+        for (mrx_renderer *sh : shards)
+            MRX_HIP(hipEventRecord(sh->ev0, sh->stream));
+        for (int i = 0; i < steps; ++i)
+            for (mrx_renderer *sh : shards)
+                MRX_HIP(sh->launch());
+        for (mrx_renderer *sh : shards)
+            MRX_HIP(hipEventRecord(sh->ev1, sh->stream));
+        return MRX_OK;
+    default:
+        return MRX_OK;
+    }
+}
+
+void shardWorkerMain(ShardWorker *w)
+{
+    const hipError_t bound = hipSetDevice(w->shards[0]->device);
+    uint32_t seen = 0;
+    int64_t lastWork = nowNs();
+    for (;;) {
+        uint32_t seq;
+        // park: spin while commands keep coming, then sleep
+        for (uint32_t it = 0;; ++it) {
+            seq = w->posted.load(std::memory_order_acquire);
+            if (seq != seen)
+                break;
+            if ((it & 255u) == 255u && nowNs() - lastWork > shardSpinNs()) {
+                w->sleeping.store(1, std::memory_order_seq_cst);
+                if (w->posted.load(std::memory_order_seq_cst) == seen)
+                    futexWait(&w->posted, seen);
+                w->sleeping.store(0, std::memory_order_relaxed);
+                continue;
+            }
+            cpuRelax();
+        }
+        seen = seq;
+        const int cmd = w->cmd;
+        if (shardTrace())
+            w->tSeen = nowNs();
+        if (cmd == kCmdExit) {
+            w->done.store(seq, std::memory_order_release);
+            return;
+        }
+        int rc = MRX_OK;
+        if (bound != hipSuccess)
+            rc = fail(MRX_E_HIP, std::string("hipSetDevice (shard worker): ") + hipGetErrorString(bound));
+        if (rc == MRX_OK)
+            rc = groupRun(w->shards, cmd, w->steps, false);
+        w->rc = rc;
+        if (rc != MRX_OK)
+            w->err = g_err;
+        if (shardTrace())
+            w->tDone = nowNs();
+        w->done.store(seq, std::memory_order_seq_cst);
+        if (w->masterSleeping.load(std::memory_order_seq_cst))
+            futexWake(&w->done);
+        lastWork = nowNs();
+    }
+}
+
+// run `cmd` on every shard of a multi-device renderer: workers in parallel, shard 0 (and any
+// shard without a worker) on the calling thread; returns the first failure
+int shardsRun(mrx_renderer *r, int cmd, int steps = 0)
+{
+    if (r->workers.empty()) {
+        // no threads: device by device from the calling thread (consecutive shards of one device as a group)
+        std::vector<mrx_renderer *> group;
+        for (size_t i = 0; i < r->shards.size(); ++i) {
+            group.push_back(r->shards[i]);
+            if (i + 1 == r->shards.size() || r->shards[i + 1]->device != r->shards[i]->device) {
+                const int rc = groupRun(group, cmd, steps, true);
+                if (rc != MRX_OK)
+                    return rc;
+                group.clear();
+            }
+        }
+        return MRX_OK;
+    }
+    const uint32_t seq = ++r->workerSeq;
+    const bool trace = shardTrace() && cmd == kCmdRender;
+    const int64_t tPost = trace ? nowNs() : 0;
+    int64_t tOwn = 0;
+    for (ShardWorker *w : r->workers) {
+        w->cmd = cmd;
+        w->steps = steps;
+        w->posted.store(seq, std::memory_order_seq_cst);
+        if (w->sleeping.load(std::memory_order_seq_cst))
+            futexWake(&w->posted);
+    }
+    int rc = groupRun(r->ownShards, cmd, steps, true);
+    if (trace)
+        tOwn = nowNs();
+    std::string err = rc != MRX_OK ? g_err : std::string();
+    for (ShardWorker *w : r->workers) {
+        // an enqueue takes microseconds: spin; a stream synchronisation may take long: sleep
+        const int64_t t0 = nowNs();
+        for (uint32_t it = 0; w->done.load(std::memory_order_acquire) != seq; ++it) {
+            if ((it & 255u) == 255u && nowNs() - t0 > 50000) {
+                w->masterSleeping.store(1, std::memory_order_seq_cst);
+                const uint32_t cur = w->done.load(std::memory_order_seq_cst);
+                if (cur != seq)
+                    futexWait(&w->done, cur);
+                w->masterSleeping.store(0, std::memory_order_relaxed);
+                continue;
+            }
+            cpuRelax();
+        }
+        if (w->rc != MRX_OK && rc == MRX_OK) {
+            rc = w->rc;
+            err = w->err;
+        }
+    }
+    if (trace) {
+        int64_t wake = 0, launch = 0;
+        for (ShardWorker *w : r->workers) {
+            wake = std::max(wake, w->tSeen - tPost);
+            launch = std::max(launch, w->tDone - w->tSeen);
+        }
+        g_trace.wake += wake;
+        g_trace.launch += launch;
+        g_trace.own += tOwn - tPost;
+        g_trace.total += nowNs() - tPost;
+        g_trace.n++;
+    }
+    if (rc != MRX_OK)
+        return fail(rc, err);
+    return MRX_OK;
+}
+
+void startShardWorkers(mrx_renderer *r)
+{
+    // One host thread per DEVICE: shards that share a device share its queues and (by default)
+    // its null stream, where concurrent launches only queue up behind the runtime's stream lock
+    // (profiles/r04_multidev_host.txt: eight threads on one null stream 48 us per step against
+    // 32 us from one thread).  The first device's shards stay with the calling thread.
+    // MRX_SHARD_THREADS=0: no threads at all; =2: a thread per shard whatever its device (the
+    // one-GPU rehearsal of a node, with a stream per shard).
+    int mode = 1;
+    if (const char *e = std::getenv("MRX_SHARD_THREADS"))
+        mode = std::atoi(e);
+    if (mode <= 0)
+        return;
+    std::vector<std::vector<mrx_renderer *>> groups;
+    for (mrx_renderer *sh : r->shards) {
+        bool placed = false;
+        for (auto &g : groups)
+            if (mode == 1 && g[0]->device == sh->device) {
+                g.push_back(sh);
+                placed = true;
+                break;
+            }
+        if (!placed)
+            groups.push_back({ sh });
+    }
+    if (groups.size() <= 1)
+        return;
+    r->ownShards = groups[0];
+    for (size_t g = 1; g < groups.size(); ++g) {
+        ShardWorker *w = new ShardWorker();
+        w->shards = groups[g];
+        w->th = std::thread(shardWorkerMain, w);
+        r->workers.push_back(w);
+    }
+}
+
+}  // namespace
+
+static void stopShardWorkers(mrx_renderer *r)
+{
+    if (r->workers.empty())
+        return;
+    const uint32_t seq = ++r->workerSeq;
+    for (ShardWorker *w : r->workers) {
+        w->cmd = kCmdExit;
+        w->posted.store(seq, std::memory_order_seq_cst);
+        futexWake(&w->posted);
+    }
+    for (ShardWorker *w : r->workers) {
+        w->th.join();
+        delete w;
+    }
+    r->workers.clear();
+}
 
 namespace {
 
@@ -1295,6 +1588,9 @@ int mrx_create(const mrx_config *cfgIn, mrx_renderer **out)
         return fail(MRX_E_INVALID, "device_ids is null while num_devices is not zero");
     if (cfg->num_devices > 64)
         return fail(MRX_E_INVALID, "more than 64 devices");
+    if (cfg->num_devices > 1 && cfg->num_devices > cfg->num_worlds)
+        return fail(MRX_E_INVALID, "more devices (" + std::to_string(cfg->num_devices) + ") than worlds (" +
+                                       std::to_string(cfg->num_worlds) + "): a shard would own no world");
     if (cfg->num_devices <= 1) {
         if (cfg->num_devices == 1 && cfg->device_ids)
             full.gpu_id = cfg->device_ids[0];
@@ -1331,6 +1627,7 @@ int mrx_create(const mrx_config *cfgIn, mrx_renderer **out)
         top->shardFirstWorld.push_back(lo);
     }
     top->shardFirstWorld.push_back(cfg->num_worlds);
+    startShardWorkers(top);
     *out = top;
     return MRX_OK;
 }
@@ -1339,6 +1636,7 @@ void mrx_destroy(mrx_renderer *r)
 {
     if (!r)
         return;
+    stopShardWorkers(r);
     for (mrx_renderer *sh : r->shards) {
         (void)hipSetDevice(sh->device);
         (void)hipStreamSynchronize(sh->stream);
@@ -1354,15 +1652,10 @@ int mrx_render(mrx_renderer *r)
 {
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
-    // several devices: one launch each, enqueued back to back from this thread -- device
-    // i + 1 is launched while device i renders; nothing here waits
-    for (mrx_renderer *sh : r->shards) {
-        const int rc = mrx_render(sh);
-        if (rc != MRX_OK)
-            return rc;
-    }
+    // several devices: one launch each, enqueued concurrently by the shards' host threads
+    // (shardsRun); on return every device has its kernel queued, nothing waits for a render
     if (!r->shards.empty())
-        return MRX_OK;
+        return shardsRun(r, kCmdRender);
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(r->launch());
     return MRX_OK;
@@ -1383,13 +1676,8 @@ int mrx_sync(mrx_renderer *r)
 {
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
-    for (mrx_renderer *sh : r->shards) {
-        const int rc = mrx_sync(sh);
-        if (rc != MRX_OK)
-            return rc;
-    }
     if (!r->shards.empty())
-        return MRX_OK;
+        return shardsRun(r, kCmdSync);
     MRX_HIP(hipSetDevice(r->device));
     MRX_HIP(hipStreamSynchronize(r->stream));
     return MRX_OK;
@@ -1454,6 +1742,12 @@ int mrx_refresh_objects(mrx_renderer *r)
     std::vector<int32_t> live(r->boundObj.size());
     if (!live.empty())
         MRX_HIP(hipMemcpy(live.data(), r->instObj.ptr, live.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // an id that names no object cannot be bound: refuse it before anything changes
+    for (size_t i = 0; i < live.size(); ++i)
+        if (live[i] >= 0 && (size_t)live[i] >= r->objFirst.size())
+            return fail(MRX_E_INVALID, "instance row " + std::to_string(i) + " holds object id " +
+                                           std::to_string(live[i]) + ", the scene has " +
+                                           std::to_string(r->objFirst.size()) + " objects");
     bool changed = false;
     for (size_t i = 0; i < live.size(); ++i)
         if (live[i] >= 0 && live[i] != r->boundObj[i]) {
@@ -1462,12 +1756,7 @@ int mrx_refresh_objects(mrx_renderer *r)
         }
     if (!changed)
         return MRX_OK;
-    const bool wasBvh = r->useBvh;
-    const int rc = bindGeometry(*r);
-    if (rc != MRX_OK)
-        return rc;
-    (void)wasBvh;
-    return MRX_OK;
+    return bindGeometry(*r);
 }
 
 int mrx_set_stream(mrx_renderer *r, void *stream)
@@ -1581,7 +1870,7 @@ int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes)
     return MRX_OK;
 }
 
-int mrx_info(mrx_renderer *r, mrx_info_t *out)
+static int infoFull(mrx_renderer *r, mrx_info_t *out)
 {
     if (!r || !out)
         return fail(MRX_E_INVALID, "null argument");
@@ -1606,6 +1895,48 @@ int mrx_info(mrx_renderer *r, mrx_info_t *out)
     return MRX_OK;
 }
 
+int mrx_info(mrx_renderer *r, mrx_info_t *out)
+{
+    // the ABI-2 entry point: its callers allocated the struct as it was then
+    return mrx_info_sized(r, out, MRX_INFO_V2_SIZE);
+}
+
+int mrx_info_sized(mrx_renderer *r, void *out, size_t size)
+{
+    if (!r || !out)
+        return fail(MRX_E_INVALID, "null argument");
+    if (size < MRX_INFO_V2_SIZE)
+        return fail(MRX_E_INVALID, "mrx_info_t size mismatch (ABI)");
+    mrx_info_t full;
+    const int rc = infoFull(r, &full);
+    if (rc != MRX_OK)
+        return rc;
+    std::memcpy(out, &full, std::min(size, sizeof full));
+    return MRX_OK;
+}
+
+int mrx_time_steps_host(mrx_renderer *r, int steps, double *us_per_step)
+{
+    if (!r || !us_per_step || steps <= 0)
+        return fail(MRX_E_INVALID, "bad argument");
+    g_trace = ShardTrace {};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < steps; ++i) {
+        const int rc = mrx_step(r);
+        if (rc != MRX_OK)
+            return rc;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    *us_per_step = std::chrono::duration<double, std::micro>(t1 - t0).count() / (double)steps;
+    if (shardTrace() && g_trace.n) {
+        const double n = (double)g_trace.n * 1000.0;
+        std::fprintf(stderr, "mrx shard trace (%lld steps, us): wake %.2f  worker launch %.2f  own launch %.2f  all enqueued %.2f\n",
+                     (long long)g_trace.n, g_trace.wake / n, g_trace.launch / n, g_trace.own / n, g_trace.total / n);
+        g_trace = ShardTrace {};
+    }
+    return mrx_sync(r);
+}
+
 int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
 {
     if (!r || !ms_total || steps < 0)
@@ -1613,20 +1944,12 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
     if (!r->shards.empty()) {
         // every device runs its `steps` launches between its own two events, all enqueued
         // before anything is waited for: the job takes as long as the slowest device
-        for (mrx_renderer *sh : r->shards) {
-            MRX_HIP(hipSetDevice(sh->device));
-            MRX_HIP(hipEventRecord(sh->ev0, sh->stream));
+        {
+            const int rc = shardsRun(r, kCmdTimed, steps);    // every device's launches from its own thread
+            if (rc != MRX_OK)
+                return rc;
         }
-        for (int i = 0; i < steps; ++i)
-            for (mrx_renderer *sh : r->shards) {
-                MRX_HIP(hipSetDevice(sh->device));
-                MRX_HIP(sh->launch());
-            }
         *ms_total = 0.0f;
-        for (mrx_renderer *sh : r->shards) {
-            MRX_HIP(hipSetDevice(sh->device));
-            MRX_HIP(hipEventRecord(sh->ev1, sh->stream));
-        }
         for (mrx_renderer *sh : r->shards) {
             float ms = 0.0f;
             MRX_HIP(hipSetDevice(sh->device));

@@ -369,6 +369,7 @@ PYBIND11_MODULE(madrona_renderer, m)
              },
              py::arg("shard") = py::none())
         .def("time_renders", &Manager::timeRenders, py::arg("steps"))
+        .def("time_steps_host", &Manager::timeStepsHost, py::arg("steps"))
         .def("mark", &Manager::mark, py::arg("which"))
         .def("elapsed_ms", &Manager::elapsedMs)
         .def("bytes_per_step", &Manager::bytesPerStep)
@@ -389,7 +390,13 @@ PYBIND11_MODULE(madrona_renderer, m)
         .def("native_handle", [](Manager &self) { return (uint64_t)self.nativeHandle(); })
         // e.g. r.set_stream(torch.cuda.current_stream().cuda_stream): pose writes and
         // step() are then ordered on that stream without a host synchronisation
-        .def("set_stream", [](Manager &self, uint64_t stream) { self.setStream((void *)stream); },
-             py::arg("stream"))
+        .def("set_stream",
+             [](Manager &self, uint64_t stream, py::object shard) {
+                 if (shard.is_none())
+                     self.setStream((void *)stream);
+                 else
+                     self.setShardStream(shard.cast<uint32_t>(), (void *)stream);
+             },
+             py::arg("stream"), py::arg("shard") = py::none())
         .def_readonly("num_agents", &Manager::numAgents);
 }

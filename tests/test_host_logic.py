@@ -25,7 +25,7 @@ def test_capi_exports_every_declared_symbol(native):
     for n in names:
         assert hasattr(lib, n), f"libmrx_hip.so does not export {n}"
     lib.mrx_abi_version.restype = ctypes.c_int
-    assert lib.mrx_abi_version() == 3
+    assert lib.mrx_abi_version() == 4
 
 
 def test_module_surface_matches_reference_bindings(native):
