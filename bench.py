@@ -44,6 +44,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# A wave64 VALU instruction occupies its SIMD for 2 cycles when several waves share the SIMD
+# (MI355X_MICROARCH.md:54 and the constants table, `v_fma_f32`: 2 cyc; one wave alone: 4).
+# Rounds 2-3 priced the BVH kernel against 4 cycles (614 G wave-instr/s) from a micro-benchmark
+# that assumed a 2.4 GHz clock; scripts/micro/valu_issue.hip (profiles/r04_valu_issue.txt)
+# measures 601 G wave-instr/s chip-wide at one wave per SIMD, 872 at two, 944 at four and 973
+# at eight for independent v_fma_f32 -- the guide's figure is the right peak: 1228.8 G.
+VALU_CYCLES_PER_WAVE64_INSTR = 2.0
 # untimed renders before the warm-up (clocks leave idle only under load); reported as `settle_s`
 SETTLE_S = float(os.environ.get("MRX_BENCH_SETTLE_S", "0.25"))
 # renders per host wait during the settle: long batches keep the card under continuous load (batches of 100
@@ -195,6 +202,23 @@ def pmc_table():
         return {}
 
 
+def bvh_kernel_hash():
+    """sha256 (16 hex) over the sources the BVH kernel is compiled from: an "sq" entry of
+    pmc_latest.json carries the hash of the build its counters were collected on
+    (scripts/pmc_sq_summary.py writes it), so a figure that no longer describes the running
+    kernel is recognised."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "madrona_renderer_amd", "csrc")
+    for name in ("bvh.hip", "bvh.hpp", "raster_dev.hpp", "raster.hpp"):
+        try:
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(tag):
     """(HBM bytes per launch, where the figure comes from) from the committed
     rocprofv3 --pmc summaries of this same command (profiles/pmc_latest.json),
@@ -235,20 +259,23 @@ def bvh_roofline(tag, kern_us, views, tiles_per_view):
     issue rate.  VALU instructions per wave come from the committed SQ-counter summary
     of exactly this workload (profiles/pmc_latest.json, "sq" of the workload's entry;
     SQ_INSTS_VALU / SQ_WAVES); the peak is what 1024 SIMDs (256 CUs x 4) issue when
-    a wave64 vector instruction occupies its SIMD for four cycles at 2.4 GHz
-    (MI355X_MICROARCH.md; measured here: v_fma_f32 4.3 cycles per wave and SIMD):
-    614.4 G wave-instructions/s."""
+    a wave64 vector instruction occupies its SIMD for two cycles at 2.4 GHz
+    (VALU_CYCLES_PER_WAVE64_INSTR above): 1228.8 G wave-instructions/s."""
     ent = pmc_table().get(tag)
     sq = ent.get("sq") if isinstance(ent, dict) else None
     if not isinstance(sq, dict) or not sq.get("valu_per_wave"):
         return None
     waves = views * tiles_per_view * 8
     valu = float(sq["valu_per_wave"]) * waves
-    peak = 256 * 4 * 2.4e9 / 4.0
+    peak = 256 * 4 * 2.4e9 / VALU_CYCLES_PER_WAVE64_INSTR
     achieved = valu / (kern_us * 1e-6)
+    # the counters describe the build they were collected on: a different kernel source since
+    # then makes the figure an estimate, and the HBM roofline stays the line's primary one
+    stale = sq.get("kernel_hash") != bvh_kernel_hash()
     return {"bound": "valu-issue", "achieved": achieved / 1e9, "peak": peak / 1e9,
             "unit": "G wave-instr/s", "frac": achieved / peak,
-            "valu_per_wave": sq["valu_per_wave"], "sq_source": sq.get("source")}
+            "valu_per_wave": sq["valu_per_wave"], "sq_source": sq.get("source"),
+            "sq_kernel_hash": sq.get("kernel_hash"), "stale": bool(stale)}
 
 
 def run_dry(a):
@@ -324,10 +351,11 @@ def run_rank(a):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def gather_leg(r, steps, views_total):
+    def gather_leg(r, steps, views_total, counts=None):
         """K steps of render + all-gather of the rank's rgb and depth slabs into the
         global tensors through sharding.gather_slabs (RCCL all_gather_into_tensor over
-        xGMI; gloo on host copies in a rehearsal)."""
+        xGMI; gloo on host copies in a rehearsal).  ``counts`` = views per rank when the
+        shards are ragged (a world count the ranks do not divide)."""
         rgb = r.rgb_tensor().to_torch()
         dep = r.depth_tensor().to_torch()
         if rehearsal:
@@ -335,30 +363,34 @@ def run_rank(a):
         else:
             stage = lambda t: t
         g_rgb = g_dep = None
+        s_rgb, s_dep = {}, {}
         for _ in range(3):
-            g_rgb = sharding.gather_slabs(stage(rgb), out=g_rgb)
-            g_dep = sharding.gather_slabs(stage(dep), out=g_dep)
+            g_rgb = sharding.gather_slabs(stage(rgb), counts=counts, out=g_rgb, scratch=s_rgb)
+            g_dep = sharding.gather_slabs(stage(dep), counts=counts, out=g_dep, scratch=s_dep)
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             r.step()
             if rehearsal:
                 r.sync()
-            g_rgb = sharding.gather_slabs(stage(rgb), out=g_rgb)
-            g_dep = sharding.gather_slabs(stage(dep), out=g_dep)
+            g_rgb = sharding.gather_slabs(stage(rgb), counts=counts, out=g_rgb, scratch=s_rgb)
+            g_dep = sharding.gather_slabs(stage(dep), counts=counts, out=g_dep, scratch=s_dep)
         torch.cuda.synchronize()
         gw = max_over_ranks(time.perf_counter() - t0)
         barrier()
         # the slab of this rank inside the gathered tensor is what it rendered
         nv = rgb.shape[0]
-        same = bool(torch.equal(g_rgb[rank * nv:(rank + 1) * nv], stage(rgb))) and \
-            bool(torch.equal(g_dep[rank * nv:(rank + 1) * nv], stage(dep)))
+        first = rank * nv if counts is None else sum(counts[:rank])
+        same = bool(torch.equal(g_rgb[first:first + nv], stage(rgb))) and \
+            bool(torch.equal(g_dep[first:first + nv], stage(dep))) and \
+            int(g_rgb.shape[0]) == views_total
         ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=coll_dev)
         if dist is not None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         return {"value": views_total * steps / gw, "unit": "views/s", "steps": steps,
                 "ms_per_step": gw * 1000.0 / steps,
-                "collective": "sharding.gather_slabs: all_gather_into_tensor of rgb + depth",
+                "collective": "sharding.gather_slabs: all_gather_into_tensor of rgb + depth" +
+                              ("" if counts is None or len(set(counts)) == 1 else " (ragged shards, padded)"),
                 "backend": dist.get_backend() if dist is not None else None,
                 "gathered_views": int(g_rgb.shape[0]), "own_slab_intact": bool(ok.item() == 1.0)}
 
@@ -433,7 +465,9 @@ def run_rank(a):
     if r.render_path() == "bvh":
         tiles = ((a.width + 63) // 64) * ((a.height + 63) // 64)
         own = bvh_roofline(workload_tag(a, n_gpus), kern_us, views, tiles)
-        if own is not None:
+        if own is not None and own["stale"]:
+            out["roofline"]["valu_issue_stale"] = own
+        elif own is not None:
             # the HBM figures stay, as frac_hbm; `frac` is against the bound that applies
             hb = out["roofline"]
             own.update({"frac_hbm": hb["frac"], "achieved_hbm_GBps": hb["achieved"], "traffic": hb["traffic"],
@@ -526,7 +560,10 @@ def run_rank(a):
                   "frac_kernel": b3 / (ms3 * 1e-3 / k3) / 1e9 / HBM_PEAK_GBPS,
                   "settle_s": 0.1, "settle_renders": settle3, "placement": r3.placement()}
         if dist is not None and n_gpus > 1:
-            strong["with_gather"] = gather_leg(r3, min(k3, 200), a.strong_worlds)
+            # (one camera per world: views per rank = worlds per rank; ragged when N does not divide)
+            per_rank = [scenes.shard_range(a.strong_worlds, q, n_gpus) for q in range(n_gpus)]
+            strong["with_gather"] = gather_leg(r3, min(k3, 200), a.strong_worlds,
+                                               counts=[h - l for l, h in per_rank])
         out["also_strong"] = strong
         del r3
 

@@ -22,31 +22,48 @@ def view_ranges(worlds, world_size):
     return out
 
 
-def gather_slabs(local, counts=None, group=None, out=None):
+def gather_slabs(local, counts=None, group=None, out=None, scratch=None):
     """All-gather per-rank output slabs along dim 0 into the global tensor.
 
-    ``local``  this rank's [views_r, ...] tensor (device tensor under nccl,
-               CPU tensor under gloo);
-    ``counts`` views per rank when they differ (ragged shards are padded to the
-               largest slab so the exchange stays one fused collective);
-    ``out``    a [world_size * max(views_r), ...] tensor of a previous call to
-               receive into again (a per-step gather allocates nothing).
+    ``local``   this rank's [views_r, ...] tensor (device tensor under nccl,
+                CPU tensor under gloo);
+    ``counts``  views per rank when they differ (ragged shards are padded to the
+                largest slab so the exchange stays one fused collective);
+    ``out``     the global [sum(views_r), ...] tensor of a previous call to
+                receive into again;
+    ``scratch`` a dict the caller keeps between calls: the padded send / receive
+                buffers of the ragged path live in it, so that a per-step gather
+                allocates nothing in either path.
     World size 1 is a no-op that returns ``local`` itself."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     if ws == 1:
         return local
+    tail = tuple(local.shape[1:])
     if counts is None or len(set(counts)) == 1:
-        shape = (ws * local.shape[0],) + tuple(local.shape[1:])
+        shape = (ws * local.shape[0],) + tail
         if out is None or tuple(out.shape) != shape:
             out = local.new_empty(shape)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
     # ragged shards: pad every slab to the largest, one fused collective, trim
+    if len(counts) != ws:
+        raise ValueError("counts has %d entries for %d ranks" % (len(counts), ws))
+    rank = dist.get_rank(group)
+    if local.shape[0] != counts[rank]:
+        raise ValueError("rank %d holds %d views, counts says %d" % (rank, local.shape[0], counts[rank]))
     top = max(counts)
-    padded = local.new_zeros((top,) + tuple(local.shape[1:]))
-    padded[:local.shape[0]] = local
-    shape = (ws * top,) + tuple(local.shape[1:])
+    if scratch is None:
+        scratch = {}
+    key = (top, ws, tail, local.dtype, local.device)
+    if scratch.get("key") != key:
+        scratch["key"] = key
+        scratch["send"] = local.new_zeros((top,) + tail)
+        scratch["recv"] = local.new_empty((ws * top,) + tail)
+    send, recv = scratch["send"], scratch["recv"]
+    send[:local.shape[0]] = local
+    dist.all_gather_into_tensor(recv, send, group=group)
+    shape = (sum(counts),) + tail
     if out is None or tuple(out.shape) != shape:
         out = local.new_empty(shape)
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return torch.cat([out[r * top:r * top + c] for r, c in enumerate(counts)], dim=0)
+    torch.cat([recv[r * top:r * top + c] for r, c in enumerate(counts)], dim=0, out=out)
+    return out

@@ -42,6 +42,16 @@ def _worker(rank, world_size, port, num_worlds, out_dir):
     counts = [b - a for a, b in sharding.view_ranges(whole.worlds, world_size)]
     rgb = sharding.gather_slabs(torch.from_numpy(o["rgb"]), counts)
     dep = sharding.gather_slabs(torch.from_numpy(o["depth"]), counts)
+    # a per-step gather reuses its buffers: the global tensor and (ragged) the padded scratch
+    keep = {}
+    again = sharding.gather_slabs(torch.from_numpy(o["rgb"]), counts, out=rgb, scratch=keep)
+    assert again.data_ptr() == rgb.data_ptr()
+    if len(set(counts)) > 1:
+        recv = keep["recv"].data_ptr()
+        third = sharding.gather_slabs(torch.from_numpy(o["rgb"]), counts, out=again, scratch=keep)
+        assert third.data_ptr() == rgb.data_ptr() and keep["recv"].data_ptr() == recv
+        with pytest.raises(ValueError):
+            sharding.gather_slabs(torch.from_numpy(o["rgb"]), counts + [1])
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
