@@ -1210,6 +1210,306 @@ void bvhTileKernel(const RasterParams p)
 #undef MRX_TLAS_HDR
 }
 
+
+// ---------------------------------------------------------------------------
+// Worlds of at most 64 triangles in at most 64 instance rows (every BASELINE scene: cube + plane
+// is 14 triangles in 2 rows; configs[4] names this path for them): the leaf set-up of the WHOLE
+// world is one 64-lane batch, so the machinery of the general kernel above -- instance
+// rectangles, per-wave queues, record slots handed out by atomics, a shared list of large
+// triangles behind a barrier -- only costs.  profiles/r04_c5bvh_pmc_sq.txt: on configs[4] a wave
+// of that kernel spends 58 % of its life at barriers; per tile one wave sets the cube's twelve
+// triangles up again and walks them while six of the eight wait.  Here:
+//   once per VIEW   wave 0: lane = instance -> TLAS records in LDS (phase I as above), then
+//                   lane = world-local triangle k -> S3-S7 set-up (setupTriangleCore, the same
+//                   call), planes + box into triRec[k], the shading record into slot k + 1 -- the
+//                   record table is the world, nothing is allocated and nothing can overflow.
+//   per tile        every wave classifies the 64 triangles against the tile on its own (lane =
+//                   triangle: box, then the planes at the tile's corner pixels, exact by
+//                   monotonicity), all eight reach the same masks and prefix sums without talking;
+//                   the (triangle, row) items of the small triangles are dealt 64 at a time round
+//                   robin over the WAVES (the general kernel walks a batch in the wave that set it
+//                   up); large triangles are rasterised by every wave over its own strip straight
+//                   from triRec (after the exact per-strip test of the CLS instantiations).  One
+//                   barrier -- walks done -- then resolve + output per strip as above.
+//   two depth buffers   tile i merges into buffer i & 1; a wave clears its strip of it after its
+//                   resolve, and the next use of that buffer lies behind the barrier of tile
+//                   i + 1: one barrier per tile instead of two.
+// The pixel test, the (1/depth, lower index) order and the records are those of the general
+// kernel, so the output is the same bit for bit.  MRX_BVH_FLAT=0 keeps such worlds on it.
+// ---------------------------------------------------------------------------
+constexpr int kFlatTris = 64;                      // triangles and instance rows per world, at most
+constexpr size_t kFlatZBytes = 2u * 64u * 64u * 8u;
+constexpr size_t flatLdsBytes(bool tex)
+{
+    return kFlatZBytes + kFlatTris * 64u + (kFlatTris + 2u) * 16u + (tex ? (kFlatTris + 2u) * kCold * 4u : 0u) + 16u +
+           (size_t)kFlatTris * kInstRecDw * 4u;
+}
+
+template <int IDS, bool TEX>
+__global__ __launch_bounds__(kWave * 8, 4)
+void bvhFlatKernel(const RasterParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int TW = 64, TH = 64, kWaves = 8, kHalves = 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x % kWave;
+    const uint32_t tilesFast = (p.nfast + TW - 1) / TW, tilesSlow = (p.nslow + TH - 1) / TH;
+    const uint32_t tilesPerView = tilesFast * tilesSlow;
+    // (XCD-aware item order and runs of a view's tiles per workgroup: as in bvhTileKernel)
+    uint32_t item = blockIdx.x;
+    if ((tilesPerView > 1 || p.bvhGroupTiles > 1) && (gridDim.x & 7u) == 0)
+        item = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t groupTiles = p.bvhGroupTiles;
+    const uint32_t groupsPerView = (tilesPerView + groupTiles - 1) / groupTiles;
+    const uint32_t view = item / groupsPerView;
+    uint32_t tile = (item - view * groupsPerView) * groupTiles;
+    uint32_t left = min(groupTiles, tilesPerView - tile);
+
+    unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);                   // [2][TH][TW]
+    float (*triRec)[16] = reinterpret_cast<float (*)[16]>(smem + kFlatZBytes);                 // [64] planes, box
+    float4 *shadeTab = reinterpret_cast<float4 *>(triRec + kFlatTris);                          // [66]: slot k + 1
+    float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kFlatTris + 2);     // [66] (TEX)
+    float *hdr = reinterpret_cast<float *>(coldTab + (TEX ? kFlatTris + 2 : 0));                // light direction
+    float *instRec = hdr + 4;                                                                    // [64][24]
+
+    const float invNear = p.invNear, invFar = p.invFar;
+    if (wave != 0) {
+        // both depth buffers, by the seven waves that have nothing to load
+        for (uint32_t i = (uint32_t)(wave - 1) * kWave + (uint32_t)lane; i < 2u * TW * TH; i += (kWaves - 1) * kWave)
+            zbuf[i] = packHit(invFar, 0u);
+    } else {
+        // ---- phase I, lane = instance row of the view's world
+        uint32_t i0, i1;
+        viewInstances(p, view, i0, i1);
+        const uint32_t nI = min(i1 - i0, (uint32_t)kFlatTris);
+        ViewConst vc;
+        loadViewConst(p, view, vc);
+        const bool hasI = (uint32_t)lane < nI;
+        uint32_t kBase = 0, firstI = 0, numI = 0;
+        if (nI != 0) {                                // (an empty world has no row to read)
+            const uint32_t row = i0 + (hasI ? (uint32_t)lane : 0u);
+            const int32_t obj = p.instObj[row];
+            const float4 o0 = reinterpret_cast<const float4 *>(p.instInfo + row)[0];   // first, count, root of the bound object
+            kBase = p.instKBase[row];
+            InstXform x;
+            instanceTransform(p, vc, row, x);
+            if (hasI) {
+                float4 *dst = reinterpret_cast<float4 *>(instRec + (size_t)lane * kInstRecDw);
+                dst[0] = make_float4(x.MV[0][0], x.MV[0][1], x.MV[0][2], x.MV[1][0]);
+                dst[1] = make_float4(x.MV[1][1], x.MV[1][2], x.MV[2][0], x.MV[2][1]);
+                dst[2] = make_float4(x.MV[2][2], x.tv[0], x.tv[1], x.tv[2]);
+                dst[3] = make_float4(x.qo[0], x.qo[1], x.qo[2], x.det);
+                dst[4] = make_float4(x.sc[0], x.sc[1], x.sc[2], __int_as_float(obj));
+                firstI = __float_as_uint(o0.x);
+                numI = __float_as_uint(o0.y);
+            }
+        }
+        // ---- lane = world-local triangle k: the instance that draws it is the row whose
+        //      [kBase, kBase + count) holds k (rows are in index order; a hidden or unbound row
+        //      keeps its range and fails the validity test of the set-up)
+        uint32_t myInst = 0, myTri = 0;
+        bool hasT = false;
+        for (uint32_t j = 0; j < nI; ++j) {
+            const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)kBase, (int)j);
+            const uint32_t nt = (uint32_t)__builtin_amdgcn_readlane((int)numI, (int)j);
+            const uint32_t ft = (uint32_t)__builtin_amdgcn_readlane((int)firstI, (int)j);
+            const bool in = (uint32_t)lane >= kb && (uint32_t)lane - kb < nt;
+            myInst = in ? j : myInst;
+            myTri = in ? ft + ((uint32_t)lane - kb) : myTri;
+            hasT = hasT || in;
+        }
+        waveLdsSync();                                // the records written above are read below
+        TriPlanes c;
+        c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
+        c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
+        bool valid = false;
+        if (hasT) {
+            const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)myInst * kInstRecDw);
+            const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
+            InstXform y;
+            y.MV[0][0] = a0.x; y.MV[0][1] = a0.y; y.MV[0][2] = a0.z; y.MV[1][0] = a0.w;
+            y.MV[1][1] = a1.x; y.MV[1][2] = a1.y; y.MV[2][0] = a1.z; y.MV[2][1] = a1.w;
+            y.MV[2][2] = a2.x; y.tv[0] = a2.y; y.tv[1] = a2.z; y.tv[2] = a2.w;
+            y.qo[0] = a3.x; y.qo[1] = a3.y; y.qo[2] = a3.z; y.det = a3.w;
+            y.sc[0] = a4.x; y.sc[1] = a4.y; y.sc[2] = a4.z;
+            const int32_t objL = __float_as_int(a4.w);
+            float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
+            valid = setupTriangleCore<false>(p, vc.lv, y, myTri, objL, (int32_t)lane, c, shade, cold);
+            shadeTab[lane + 1] = make_float4(shade[0], shade[1], shade[2], __int_as_float(lane));
+            if (TEX && valid && __float_as_int(shade[1]) >= 0) {
+                // (u/v planes as the general kernel derives them: uvPlanes() from the edge planes and |1/d|)
+                const float4 *tsrc = reinterpret_cast<const float4 *>(p.tris + myTri);
+                const float4 t2 = tsrc[2], t3 = tsrc[3];
+                const float4 texDesc = reinterpret_cast<const float4 *>(p.triMats + myTri)[3];
+                const float uv[6] = { t2.y, t2.z, t2.w, t3.x, t3.y, t3.z };
+                float uvp[6];
+                uvPlanes(c, cold[0], uv, uvp);
+                float4 *cdst = reinterpret_cast<float4 *>(coldTab[lane + 1]);
+                cdst[0] = make_float4(uvp[0], uvp[1], uvp[2], uvp[3]);
+                cdst[1] = make_float4(uvp[4], uvp[5], cold[6], cold[7]);
+                cdst[2] = make_float4(cold[8], texDesc.x, texDesc.y, texDesc.z);
+            }
+        }
+        {
+            // a triangle that cannot own a pixel gets a box nothing meets
+            const float inf = __builtin_inff();
+            float4 *dst = reinterpret_cast<float4 *>(triRec[lane]);
+            dst[0] = make_float4(c.A0, c.A1, c.A2, c.Dx);
+            dst[1] = make_float4(c.B0, c.B1, c.B2, c.Dy);
+            dst[2] = make_float4(c.C0, c.C1, c.C2, c.Dc);
+            dst[3] = valid ? make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1) : make_float4(inf, -inf, inf, -inf);
+        }
+    }
+    __syncthreads();
+
+    const int lx = lane & 7, ly = lane >> 3;
+    const int smallArea = p.bvhSmallArea;
+    const uint32_t lowKey = ((~(uint32_t)lane & kKeyMask) << kSlotBits) | ((uint32_t)lane + 1u);
+    uint32_t buf = 0;
+    for (;;) {
+        const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
+        const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
+        const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
+        unsigned long long *zb = zbuf + (size_t)buf * (TW * TH);
+        // ---- classification, lane = triangle (every wave for itself)
+        TriPlanes c;
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(triRec[lane]);
+            const float4 pa = src[0], pb = src[1], pc = src[2], bb = src[3];
+            c.A0 = pa.x; c.A1 = pa.y; c.A2 = pa.z; c.Dx = pa.w;
+            c.B0 = pb.x; c.B1 = pb.y; c.B2 = pb.z; c.Dy = pb.w;
+            c.C0 = pc.x; c.C1 = pc.y; c.C2 = pc.z; c.Dc = pc.w;
+            c.bbX0 = bb.x; c.bbX1 = bb.y; c.bbY0 = bb.z; c.bbY1 = bb.w;
+        }
+        bool live = c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
+        {
+            const float eMax0 = __builtin_fmaf(c.A0, c.A0 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B0, c.B0 >= 0.0f ? TY1 : TY0, c.C0));
+            const float eMax1 = __builtin_fmaf(c.A1, c.A1 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B1, c.B1 >= 0.0f ? TY1 : TY0, c.C1));
+            const float eMax2 = __builtin_fmaf(c.A2, c.A2 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B2, c.B2 >= 0.0f ? TY1 : TY0, c.C2));
+            const float itMax = __builtin_fmaf(c.Dx, c.Dx >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.Dy, c.Dy >= 0.0f ? TY1 : TY0, c.Dc));
+            const float itMin = __builtin_fmaf(c.Dx, c.Dx >= 0.0f ? TX0 : TX1, __builtin_fmaf(c.Dy, c.Dy >= 0.0f ? TY0 : TY1, c.Dc));
+            live = live && fminf(fminf(eMax0, eMax1), eMax2) >= 0.0f && itMax > invFar && itMin <= invNear;
+        }
+        const float kTrim = 0.96875f;
+        const float fx0 = ceilf(fmaxf(c.bbX0 + kTrim, TX0)), fx1 = floorf(fminf(c.bbX1 - kTrim, TX1));
+        const float fy0 = ceilf(fmaxf(c.bbY0 + kTrim, TY0)), fy1 = floorf(fminf(c.bbY1 - kTrim, TY1));
+        live = live && fx0 <= fx1 && fy0 <= fy1;
+        const int ix0 = live ? (int)fx0 : 0, iy0 = live ? (int)fy0 : 0;
+        const int bw = live ? (int)fx1 - ix0 + 1 : 0, bh = live ? (int)fy1 - iy0 + 1 : 0;
+        const bool small = live && bw * bh <= smallArea;
+        const bool big = live && !small;
+        // ---- small triangles by (triangle, row of its box), the items dealt over waves and lanes
+        {
+            const int rowsMine = small ? bh : 0;
+            const int incl = waveInclusiveSum(rowsMine);
+            const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+            const int packedBox = ix0 | (bw << 16);
+            for (int item0 = wave * kWave; item0 < total; item0 += kWaves * kWave) {
+                const int j = item0 + lane;
+                const bool act = j < total;
+                int t = 0;
+#pragma unroll
+                for (int step = kWave / 2; step >= 1; step >>= 1) {
+                    const int probe = __builtin_amdgcn_ds_bpermute((t + step - 1) << 2, incl);
+                    t += probe <= j ? step : 0;
+                }
+                t = act ? t : 0;
+                const int src = t << 2;
+                const int inclT = __builtin_amdgcn_ds_bpermute(src, incl);
+                const int rowsT = __builtin_amdgcn_ds_bpermute(src, rowsMine);
+                const int boxT = __builtin_amdgcn_ds_bpermute(src, packedBox);
+                const int y0T = __builtin_amdgcn_ds_bpermute(src, iy0);
+                const uint32_t lowT = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lowKey);
+#define MRX_GATHER(v) __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v)))
+                const f32x2 A01 = { MRX_GATHER(c.A0), MRX_GATHER(c.A1) }, A2D = { MRX_GATHER(c.A2), MRX_GATHER(c.Dx) };
+                const f32x2 B01 = { MRX_GATHER(c.B0), MRX_GATHER(c.B1) }, B2D = { MRX_GATHER(c.B2), MRX_GATHER(c.Dy) };
+                const f32x2 C01 = { MRX_GATHER(c.C0), MRX_GATHER(c.C1) }, C2D = { MRX_GATHER(c.C2), MRX_GATHER(c.Dc) };
+#undef MRX_GATHER
+                const int xBeg = boxT & 0xFFFF, xEnd = xBeg + (boxT >> 16);
+                const int sy = y0T + (j - (inclT - rowsT));
+                const float py = (float)sy;
+                const f32x2 yy = { py, py };
+                const f32x2 r01 = fma2(B01, yy, C01);
+                const f32x2 r2d = fma2(B2D, yy, C2D);
+                unsigned long long *zline = zb + (sy - (int)tileY0) * TW - (int)tileX0;
+                for (int sx = xBeg; __ballot(act && sx < xEnd) != 0; sx += 4) {
+                    if (act && sx < xEnd) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const float px = (float)(sx + q4);
+                            const f32x2 pp = { px, px };
+                            const f32x2 e01 = fma2(A01, pp, r01);
+                            const f32x2 e2d = fma2(A2D, pp, r2d);
+                            if (sx + q4 < xEnd && fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f &&
+                                e2d.y > invFar && e2d.y <= invNear)
+                                atomicMax(zline + sx + q4, packHit(e2d.y, lowT));
+                        }
+                    }
+                }
+            }
+        }
+        // ---- large triangles: this wave's strip, each 32x8 half after the exact test of the
+        //      triangle's planes at the half's most favourable corner pixel (lane = triangle)
+        {
+            const int bx0 = ix0 - (int)tileX0, bx1 = bx0 + bw - 1;
+            const int by0 = iy0 - (int)tileY0, by1 = by0 + bh - 1;
+            const bool rows = big && by0 <= 8 * wave + 7 && by1 >= 8 * wave;
+            const float y0 = TY0 + (float)(8 * wave), y1 = y0 + 7.0f;
+            const float r0 = __builtin_fmaf(c.B0, c.B0 >= 0.0f ? y1 : y0, c.C0);
+            const float r1 = __builtin_fmaf(c.B1, c.B1 >= 0.0f ? y1 : y0, c.C1);
+            const float r2 = __builtin_fmaf(c.B2, c.B2 >= 0.0f ? y1 : y0, c.C2);
+            const float dMax = __builtin_fmaf(c.Dy, c.Dy >= 0.0f ? y1 : y0, c.Dc);
+            const float dMin = __builtin_fmaf(c.Dy, c.Dy >= 0.0f ? y0 : y1, c.Dc);
+#pragma unroll
+            for (int hf = 0; hf < kHalves; ++hf) {
+                const float x0 = TX0 + (float)(32 * hf), x1 = x0 + 31.0f;
+                const float e0 = __builtin_fmaf(c.A0, c.A0 >= 0.0f ? x1 : x0, r0);
+                const float e1 = __builtin_fmaf(c.A1, c.A1 >= 0.0f ? x1 : x0, r1);
+                const float e2 = __builtin_fmaf(c.A2, c.A2 >= 0.0f ? x1 : x0, r2);
+                const float iMax = __builtin_fmaf(c.Dx, c.Dx >= 0.0f ? x1 : x0, dMax);
+                const float iMin = __builtin_fmaf(c.Dx, c.Dx >= 0.0f ? x0 : x1, dMin);
+                const bool reg = fminf(fminf(e0, e1), e2) >= 0.0f && iMax > invFar && iMin <= invNear;
+                uint64_t act = __ballot(rows && reg && bx0 <= 32 * hf + 31 && bx1 >= 32 * hf);
+                if (act == 0)
+                    continue;
+                const float py = (float)(tileY0 + 8u * wave + ly);
+                const f32x2 yy = { py, py };
+                unsigned long long *zrow = zb + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
+                for (; act != 0; act &= act - 1) {
+                    const int l = __builtin_ctzll(act);
+                    const PlanePairs q = loadPlanes(triRec, l);
+                    const uint32_t lowv = ((~(uint32_t)l & kKeyMask) << kSlotBits) | ((uint32_t)l + 1u);
+                    const f32x2 r01 = fma2(q.B01, yy, q.C01);
+                    const f32x2 r2d = fma2(q.B2D, yy, q.C2D);
+#pragma unroll
+                    for (int b = 0; b < kRegionBlocks; ++b) {
+                        const float px = (float)(tileX0 + 32 * hf + 4 * lx + b);
+                        const f32x2 pp = { px, px };
+                        const f32x2 e01 = fma2(q.A01, pp, r01);
+                        const f32x2 e2d = fma2(q.A2D, pp, r2d);
+                        if (fminf(fminf(e01.x, e01.y), e2d.x) >= 0.0f && e2d.y > invFar && e2d.y <= invNear)
+                            atomicMax(zrow + b, packHit(e2d.y, lowv));
+                    }
+                }
+            }
+        }
+        __syncthreads();                              // every walk into this tile's buffer is done
+        {
+            KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(pk));
+            const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
+            resolveStrip<IDS, TEX, TW, TH, true>(ra, zb, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
+        }
+        if (--left == 0)
+            break;
+        // this wave's strip of the buffer, for the tile after the next (behind the next tile's barrier)
+        for (int i = lane; i < TW * 8; i += kWave)
+            zb[8 * wave * TW + i] = packHit(invFar, 0u);
+        buf ^= 1u;
+        ++tile;
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -1235,6 +1535,38 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
         return hipSuccess;
     const int ids = p.ids == nullptr ? 0 : p.idsAreSegmask ? 2 : 1;
     const bool tex = p.anyTextured != 0;
+    if (p.bvhFlat) {
+        // worlds of at most 64 triangles in at most 64 rows: one set-up per view (bvhFlatKernel)
+        const uint32_t tpv = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
+        const uint32_t gt = std::max<uint32_t>(1u, std::min<uint32_t>(p.bvhGroupTiles, tpv));
+        const dim3 grid(p.numViews * ((tpv + gt - 1) / gt)), block(kWave * 8);
+        int dev = 0;
+        const hipError_t ge = hipGetDevice(&dev);
+        if (ge != hipSuccess)
+            return ge;
+        if (dev < 0 || dev >= kMaxDevices)
+            return hipErrorInvalidDevice;
+#define MRX_FLAT(I, T)                                                                          \
+    do {                                                                                       \
+        static bool allowed[kMaxDevices] = {};                                                 \
+        {                                                                                      \
+            std::lock_guard<std::mutex> guard(attrMutex);                                      \
+            if (!allowed[dev]) {                                                               \
+                const hipError_t e = hipFuncSetAttribute((const void *)bvhFlatKernel<I, T>,   \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)flatLdsBytes(T)); \
+                if (e != hipSuccess)                                                           \
+                    return e;                                                                  \
+                allowed[dev] = true;                                                           \
+            }                                                                                  \
+        }                                                                                      \
+        bvhFlatKernel<I, T><<<grid, block, flatLdsBytes(T), stream>>>(p);                      \
+    } while (0)
+        if (ids == 2) { if (tex) MRX_FLAT(2, true); else MRX_FLAT(2, false); }
+        else if (ids == 1) { if (tex) MRX_FLAT(1, true); else MRX_FLAT(1, false); }
+        else { if (tex) MRX_FLAT(0, true); else MRX_FLAT(0, false); }
+#undef MRX_FLAT
+        return hipGetLastError();
+    }
     // tile shape: p.bvhTile = 0 (64x64), 1 (64x32: TW 64, TH 32), 2 (32x32)
     const int tw = p.bvhTile == 2 ? 32 : 64, th = p.bvhTile == 0 ? 64 : 32;
     const uint32_t tilesPerView = ((p.nfast + tw - 1) / tw) * ((p.nslow + th - 1) / th);

@@ -708,6 +708,12 @@ int chooseBvhGroups(mrx_renderer &r)
     RasterParams &p = r.params;
     const uint32_t nviews = p.numViews, maxWorldInst = r.info.max_world_instances;
     p.bvhGroupViews = 1;
+    // worlds that fit one 64-lane set-up take the flat kernel (bvh.hip): 64x64 tiles, one view per workgroup
+    p.bvhFlat = (p.bvhTile == 0 && r.info.max_world_triangles <= 64u && maxWorldInst <= 64u) ? 1u : 0u;
+    if (const char *dbg = std::getenv("MRX_BVH_FLAT"))
+        p.bvhFlat = p.bvhFlat && std::atoi(dbg) != 0;
+    if (p.bvhFlat)
+        return MRX_OK;
     int cus = 0;
     MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
     const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);

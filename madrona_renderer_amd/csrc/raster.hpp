@@ -154,6 +154,9 @@ struct RasterParams {
     // views on the others; bits 17..19: wave-priority mode of the younger workgroups (bvh.hip; 0 off); bits 20..31:
     // the index of the first workgroup that is a CU's second (= the number of CUs)
     uint32_t bvhGroupViews;
+    // every world holds at most 64 triangles in at most 64 instance rows: the kernel that sets a view's
+    // triangles up once and shares the per-tile work among all waves (bvh.hip, bvhFlatKernel; MRX_BVH_FLAT=0: never)
+    uint32_t bvhFlat;
 };
 
 // ---- the argument header of the group kernel's fast prologue (raster.hip, FAST) -------------------------------------
