@@ -255,7 +255,7 @@ struct SetupArgs {
     int32_t transposed;
 };
 
-template <int IDS, bool TEX, int TW, int TH, bool FINAL>
+template <int IDS, bool TEX, int TW, int TH, bool FINAL, int ZS = TW>
 __device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long long *zbuf, const float4 *shadeTab,
                                              const float (*coldTab)[kCold], uint32_t view, uint32_t tileX0,
                                              uint32_t tileY0, int wave, int lane)
@@ -275,7 +275,7 @@ __device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long 
     const uint32_t fy = tileY0 + 8u * wave + ly;
 #pragma unroll
     for (int hf = 0; hf < kHalves; ++hf) {
-        unsigned long long *zrow = zbuf + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
+        unsigned long long *zrow = zbuf + (8 * wave + ly) * ZS + 32 * hf + 4 * lx;
         const uint32_t fx0 = tileX0 + hf * 32 + 4 * lx;
         const size_t o = tileBase + (size_t)(8u * wave + ly) * p.nfast + hf * 32 + 4 * lx;
         uint32_t rgba[kRegionBlocks], low[kRegionBlocks], itBits[kRegionBlocks], texSlot[kRegionBlocks];
@@ -1238,7 +1238,19 @@ void bvhTileKernel(const RasterParams p)
 // kernel, so the output is the same bit for bit.  MRX_BVH_FLAT=0 keeps such worlds on it.
 // ---------------------------------------------------------------------------
 constexpr int kFlatTris = 64;                      // triangles and instance rows per world, at most
-constexpr size_t kFlatZBytes = 2u * 64u * 64u * 8u;
+// Row stride of the flat kernel's depth buffers, in pixels: 64 + 1.  A lane of a strip pass owns pixels
+// (4 lx + b, ly); with a stride of 64 pixels = 128 dwords the eight rows of a strip fall on the same banks
+// (ds_read_b64: 32 lanes per LDS cycle, bank = dword mod 64 -- a 4-way conflict on every access of the large
+// pass, the resolve and the clear; profiles/r04_c5bvh_pmc_sq.txt: conflict cycles = half of all LDS cycles).
+// 130 dwords = 2 mod 64 puts the four rows of a lane group on four different bank pairs -- and measures 1.5 %
+// SLOWER on every shape (configs[4] 520-527 -> 535-538 us, 4096 x 128^2 149.3 -> 151.4: rows that alternate
+// between 8- and 16-byte alignment cost the resolve and the clear their 16-byte LDS accesses, and the LDS pipe
+// is not what these tiles wait for).  Kept as a build switch; 64 is the default.
+#ifndef MRX_FLAT_ZS
+#define MRX_FLAT_ZS 64
+#endif
+constexpr int kFlatZS = MRX_FLAT_ZS;
+constexpr size_t kFlatZBytes = 2u * 64u * kFlatZS * 8u;
 constexpr size_t flatLdsBytes(bool tex)
 {
     return kFlatZBytes + kFlatTris * 64u + (kFlatTris + 2u) * 16u + (tex ? (kFlatTris + 2u) * kCold * 4u : 0u) + 16u +
@@ -1272,10 +1284,18 @@ void bvhFlatKernel(const RasterParams p)
     float *hdr = reinterpret_cast<float *>(coldTab + (TEX ? kFlatTris + 2 : 0));                // light direction
     float *instRec = hdr + 4;                                                                    // [64][24]
 
+    unsigned long long *stamps = (MRX_BVH_DIAG && p.debugStamps && wave < 4)
+        ? p.debugStamps + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
+#define MRX_STAMP(i)                                                           \
+    do {                                                                       \
+        if (MRX_BVH_DIAG && stamps && lane == 0)                               \
+            stamps[i] = __builtin_amdgcn_s_memrealtime();                      \
+    } while (0)
+    MRX_STAMP(0);
     const float invNear = p.invNear, invFar = p.invFar;
     if (wave != 0) {
         // both depth buffers, by the seven waves that have nothing to load
-        for (uint32_t i = (uint32_t)(wave - 1) * kWave + (uint32_t)lane; i < 2u * TW * TH; i += (kWaves - 1) * kWave)
+        for (uint32_t i = (uint32_t)(wave - 1) * kWave + (uint32_t)lane; i < 2u * kFlatZS * TH; i += (kWaves - 1) * kWave)
             zbuf[i] = packHit(invFar, 0u);
     } else {
         // ---- phase I, lane = instance row of the view's world
@@ -1360,7 +1380,9 @@ void bvhFlatKernel(const RasterParams p)
             dst[3] = valid ? make_float4(c.bbX0, c.bbX1, c.bbY0, c.bbY1) : make_float4(inf, -inf, inf, -inf);
         }
     }
+    MRX_STAMP(7);
     __syncthreads();
+    MRX_STAMP(1);
 
     const int lx = lane & 7, ly = lane >> 3;
     const int smallArea = p.bvhSmallArea;
@@ -1370,7 +1392,7 @@ void bvhFlatKernel(const RasterParams p)
         const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
         const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
         const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
-        unsigned long long *zb = zbuf + (size_t)buf * (TW * TH);
+        unsigned long long *zb = zbuf + (size_t)buf * (kFlatZS * TH);
         // ---- classification, lane = triangle (every wave for itself)
         TriPlanes c;
         {
@@ -1431,7 +1453,7 @@ void bvhFlatKernel(const RasterParams p)
                 const f32x2 yy = { py, py };
                 const f32x2 r01 = fma2(B01, yy, C01);
                 const f32x2 r2d = fma2(B2D, yy, C2D);
-                unsigned long long *zline = zb + (sy - (int)tileY0) * TW - (int)tileX0;
+                unsigned long long *zline = zb + (sy - (int)tileY0) * kFlatZS - (int)tileX0;
                 for (int sx = xBeg; __ballot(act && sx < xEnd) != 0; sx += 4) {
                     if (act && sx < xEnd) {
 #pragma unroll
@@ -1448,6 +1470,7 @@ void bvhFlatKernel(const RasterParams p)
                 }
             }
         }
+        MRX_STAMP(2);
         // ---- large triangles: this wave's strip, each 32x8 half after the exact test of the
         //      triangle's planes at the half's most favourable corner pixel (lane = triangle)
         {
@@ -1474,7 +1497,7 @@ void bvhFlatKernel(const RasterParams p)
                     continue;
                 const float py = (float)(tileY0 + 8u * wave + ly);
                 const f32x2 yy = { py, py };
-                unsigned long long *zrow = zb + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
+                unsigned long long *zrow = zb + (8 * wave + ly) * kFlatZS + 32 * hf + 4 * lx;
                 for (; act != 0; act &= act - 1) {
                     const int l = __builtin_ctzll(act);
                     const PlanePairs q = loadPlanes(triRec, l);
@@ -1493,21 +1516,26 @@ void bvhFlatKernel(const RasterParams p)
                 }
             }
         }
+        MRX_STAMP(3);
         __syncthreads();                              // every walk into this tile's buffer is done
+        MRX_STAMP(4);
         {
             KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pk));
             const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
-            resolveStrip<IDS, TEX, TW, TH, true>(ra, zb, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
+            resolveStrip<IDS, TEX, TW, TH, true, kFlatZS>(ra, zb, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
         }
+        MRX_STAMP(5);
         if (--left == 0)
             break;
         // this wave's strip of the buffer, for the tile after the next (behind the next tile's barrier)
-        for (int i = lane; i < TW * 8; i += kWave)
-            zb[8 * wave * TW + i] = packHit(invFar, 0u);
+        for (int i = lane; i < kFlatZS * 8; i += kWave)
+            zb[8 * wave * kFlatZS + i] = packHit(invFar, 0u);
         buf ^= 1u;
         ++tile;
     }
+    MRX_STAMP(6);
+#undef MRX_STAMP
 }
 
 }  // namespace

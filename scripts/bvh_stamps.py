@@ -15,6 +15,8 @@ cubes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 worlds = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 if cubes > 0:
     desc = meshes.cube_field(worlds, cubes, textured=os.environ.get('TEXTURED') == '1')
+elif os.environ.get("SHAPE") == "c3":
+    desc = scenes.synthetic_scene(worlds, width=128, height=128, with_wall=True)
 else:           # cubes = 0: the BASELINE configs[4] shape (256x256 Raytracer, textured cube + plane), `worlds` views
     desc = scenes.synthetic_scene(worlds, width=256, height=256, textured=True, render_mode="Raytracer")
 r = scenes.make_renderer(desc)
@@ -29,6 +31,29 @@ tiles = ((desc.width + 63) // 64) * ((desc.height + 63) // 64) if cubes == 0 els
 buf = np.zeros(worlds * tiles * 4 * 8, np.uint64)
 n = lib.mrx_debug_stamps(ctypes.c_void_p(r.native_handle()), buf.ctypes.data, buf.size)
 st = buf[:n].reshape(-1, 4, 8).astype(np.int64)
+st = st[st[:, 0, 0] != 0]                 # (groups of tiles: fewer workgroups than tiles)
+if os.environ.get("FLAT") == "1":
+    # bvhFlatKernel: 0 entry, 7 wave reaches the set-up barrier, 1 barrier passed, then of the LAST tile of the group:
+    # 2 classification + small walk done, 3 large pass done, 4 barrier passed, 5 resolve + stores issued, 6 exit
+    t0 = st[:, :, 0].min()
+    us = (st - t0) / 100.0
+    order = [0, 7, 1, 2, 3, 4, 5, 6]
+    names = ["entry", "at set-up barrier", "set-up barrier passed", "last tile: small walk done", "large pass done",
+             "barrier passed", "resolve done", "exit"]
+    for w in range(4):
+        print("wave %d" % w)
+        for i, nm in zip(order, names):
+            v = us[:, w, i]
+            print(f"  {nm:28s} p10 {np.percentile(v, 10):7.2f}  p50 {np.median(v):7.2f}  p90 {np.percentile(v, 90):7.2f}")
+    life = us[:, :, 6] - us[:, :, 0]
+    print("workgroup life p50 %.2f us, set-up (entry -> barrier passed) p50 %.2f, per tile (life - set-up) / tiles-per-group" %
+          (np.median(life), np.median(us[:, :, 1] - us[:, :, 0])))
+    d = {"walk->large": us[:, :, 3] - us[:, :, 2], "large->barrier": us[:, :, 4] - us[:, :, 3],
+         "barrier->resolve": us[:, :, 5] - us[:, :, 4]}
+    for k, v in d.items():
+        print(f"  last tile {k:18s} p50 {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}")
+    print("kernel span %.1f us" % us[:, :, 6].max())
+    sys.exit(0)
 t0 = st[:, :, 0].min()
 us = (st - t0) / 100.0
 names = ["entry", "TLAS built (barrier)", "produce done", "barrier 1", "large pass done", "resolve done (barrier 3)", "exit"]
