@@ -312,6 +312,14 @@ int64_t mrx_describe_obj_materials(const char *path, char *json, uint64_t capaci
 int mrx_blas_check(const float *tri_pos /*[T][9]*/, uint32_t num_tris, uint32_t *num_nodes,
                    uint32_t *depth, uint32_t *num_leaves);
 void mrx_free(void *p);
+/*    The dispatch rules that depend on the size of the device, as pure functions (host only): the triangles
+ *    per world from which the default dispatch takes the BVH path for a batch of `num_views` views of
+ *    width x height pixels on a device of `num_cus` compute units (`base` = the general threshold, 0 = the
+ *    built-in 129), and the workgroups of the raster group kernel from which a launch counts as filling the
+ *    chip.  mrx_create reads the CU count from the device (hipDeviceAttributeMultiprocessorCount). */
+uint32_t mrx_dispatch_min_tris(uint32_t base, uint32_t num_views, int textured, uint32_t width, uint32_t height,
+                               uint32_t num_cus);
+uint32_t mrx_group_fill(uint32_t num_cus);
 
 int mrx_device_count(void);
 int mrx_abi_version(void);

@@ -714,9 +714,7 @@ int chooseBvhGroups(mrx_renderer &r)
         p.bvhFlat = p.bvhFlat && std::atoi(dbg) != 0;
     if (p.bvhFlat)
         return MRX_OK;
-    int cus = 0;
-    MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
-    const uint32_t resident = 2u * (uint32_t)std::max(cus, 1);
+    const uint32_t resident = 2u * std::max(p.numCUs, 1u);
     const uint32_t tpv = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
     if (tpv == 1 && p.bvhTile == 0 && maxWorldInst <= p.bvhPassInst) {
         const bool tex = p.anyTextured != 0;
@@ -810,11 +808,10 @@ int bindGeometry(mrx_renderer &r)
                 break;
             }
         const uint32_t nviews = (uint32_t)viewWorld.size();
-        // (textured worlds: the same up to 640 views -- 512 views of 74 triangles 13.0 against 15.5 us -- and at 1024
-        // views only from ~115 triangles on, left at the general threshold)
-        if (!std::getenv("MRX_BVH_MIN_TRIS") && r.params.nfast <= 64 && r.params.nslow <= 64)
-            minTris = nviews <= 640 ? std::min(minTris, 65u)
-                      : nviews <= 1024 && !anyTex ? std::min(minTris, 91u) : minTris;
+        // (textured worlds: the same up to 2.5 views per CU -- 512 views of 74 triangles 13.0 against 15.5 us -- and at
+        // 4 per CU only from ~115 triangles on, left at the general threshold; raster.hpp bvhDispatchMinTris)
+        if (!std::getenv("MRX_BVH_MIN_TRIS"))
+            minTris = bvhDispatchMinTris(minTris, nviews, anyTex, r.params.nfast, r.params.nslow, r.params.numCUs);
     }
     r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= minTris);
     if (r.useBvh && maxWorldTris > kBvhMaxWorldTris)
@@ -1222,6 +1219,13 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
     p.depth = r.depth.ptr;
     p.ids = wantIds ? r.ids.ptr : nullptr;
     p.numViews = nviews;
+    {
+        int cus = 0;
+        MRX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r.device));
+        p.numCUs = (uint32_t)std::max(cus, 1);
+        if (const char *dbg = std::getenv("MRX_FAKE_CUS"))      // tests: the launch shapes of a smaller device
+            p.numCUs = (uint32_t)std::max(1, std::atoi(dbg));
+    }
     p.nfast = nfast;
     p.nslow = nslow;
     p.tilesFast = (nfast + 63) / 64;
@@ -1331,7 +1335,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         p.bvhPassInst = std::min<uint32_t>(512u, std::max<uint32_t>(8u, (uint32_t)std::atoi(dbg) / 8u * 8u));
     // Views of several tiles whose world fits one TLAS pass: a workgroup renders a run of the view's
     // tiles over one TLAS build (bvh.hip).  As long a run as leaves one full generation of resident
-    // workgroups (two per CU: 512) -- measured, profiles/r03_bvh_group_tiles.txt: 512 views of 256x256
+    // workgroups (two per CU: 512 on 256 CUs) -- measured, profiles/r03_bvh_group_tiles.txt: 512 views of 256x256
     // cube+plane 155 -> 119 us at 16 tiles per group, 1024 views of 128x128 73 -> 62 us at 4, and
     // every shape loses as soon as the groups no longer fill the chip.
     p.bvhGroupTiles = 1;
@@ -1339,7 +1343,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         const uint32_t tw = p.bvhTile == 2 ? 32 : 64, thh = p.bvhTile == 0 ? 64 : 32;
         const uint32_t tpv = ((nfast + tw - 1) / tw) * ((nslow + thh - 1) / thh);
         uint32_t g = 1;
-        while (g < 16u && g * 2u <= tpv && (uint64_t)nviews * ((tpv + 2u * g - 1) / (2u * g)) >= 512u)
+        while (g < 16u && g * 2u <= tpv && (uint64_t)nviews * ((tpv + 2u * g - 1) / (2u * g)) >= 2u * p.numCUs)
             g *= 2;
         p.bvhGroupTiles = std::max(1u, g);
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_TILES"))
@@ -2168,6 +2172,14 @@ int64_t mrx_describe_obj_materials(const char *path, char *json, uint64_t capaci
     std::memcpy(json, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
 }
+
+uint32_t mrx_dispatch_min_tris(uint32_t base, uint32_t num_views, int textured, uint32_t width, uint32_t height,
+                               uint32_t num_cus)
+{
+    return mrx::bvhDispatchMinTris(base ? base : mrx::kBvhMinTris, num_views, textured != 0, width, height, num_cus);
+}
+
+uint32_t mrx_group_fill(uint32_t num_cus) { return mrx::groupFill(num_cus); }
 
 int mrx_blas_check(const float *tri_pos, uint32_t num_tris, uint32_t *num_nodes, uint32_t *depth,
                    uint32_t *num_leaves)

@@ -1096,7 +1096,7 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
         // Small batches shrink the workgroups again until there are ~4 per CU.
         const uint32_t tpv = p.tilesFast * p.tilesSlow;
         const uint32_t maxTiles = (uint32_t)groupTilesMax(slots);
-        constexpr uint32_t kFill = 1024;          // 256 CUs x 4 resident workgroups
+        const uint32_t kFill = groupFill(p.numCUs);    // 4 resident workgroups per CU: 1024 on 256 CUs
         RasterParams q = p;
         uint32_t vg = 1, ct = tpv, gpv = 1;
         if (tpv == 1) {

@@ -157,6 +157,9 @@ struct RasterParams {
     // every world holds at most 64 triangles in at most 64 instance rows: the kernel that sets a view's
     // triangles up once and shares the per-tile work among all waves (bvh.hip, bvhFlatKernel; MRX_BVH_FLAT=0: never)
     uint32_t bvhFlat;
+    // compute units of the device the renderer runs on (hipDeviceAttributeMultiprocessorCount at creation):
+    // every "does the batch fill the chip" decision of the launchers follows from it (groupFill below)
+    uint32_t numCUs;
 };
 
 // ---- the argument header of the group kernel's fast prologue (raster.hip, FAST) -------------------------------------
@@ -214,6 +217,29 @@ enum KernelVariant : int32_t {
     kVariantRaster = 3,      // never the BVH path (group kernel, chunked kernel above 256)
     kNumVariants
 };
+
+// ---- launch-shape constants as functions of the device (they were MI355X literals) ----------------
+// Workgroups of the group kernel a launch needs before the chip counts as full: a CU holds 2048 threads = four
+// workgroups of 512 (the untextured kernel; the textured one has 256 threads and longer tiles -- same target).
+inline uint32_t groupFill(uint32_t numCUs) { return 4u * (numCUs ? numCUs : 256u); }
+// Triangles per world from which the default dispatch takes the BVH path (mrx_api.cpp bindGeometry).  `base` is the
+// general threshold (kBvhMinTris or MRX_BVH_MIN_TRIS).  Small batches of one-tile views cross earlier, because up to two
+// workgroups per CU the BVH kernel's launch costs what its slowest workgroup costs while the raster kernels' 128-slot
+// shape pays for its slots -- measured on 256 CUs (profiles/r03_bvh_threshold.txt): from 65 triangles up to 640 views =
+// 2.5 per CU (512 views of 74 triangles 10.7 against 12.3 us, textured 13.0 against 15.5), from 91 up to 1024 = 4 per CU
+// for untextured worlds (1024 views of 98 triangles 18.0 against 18.6); larger batches cross at `base`.
+inline uint32_t bvhDispatchMinTris(uint32_t base, uint32_t numViews, bool anyTextured, uint32_t nfast, uint32_t nslow,
+                                   uint32_t numCUs)
+{
+    const uint32_t cus = numCUs ? numCUs : 256u;
+    if (nfast > 64u || nslow > 64u)
+        return base;
+    if (2ull * numViews <= 5ull * cus)
+        return base < 65u ? base : 65u;
+    if (numViews <= 4u * cus && !anyTextured)
+        return base < 91u ? base : 91u;
+    return base;
+}
 
 hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
                         int32_t variant, hipStream_t stream);

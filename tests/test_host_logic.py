@@ -343,3 +343,30 @@ def test_oracle_spare_rows_and_rebinding(oracle_mod):
     fs.inst_obj[0] = 0
     again = fs.render()
     assert np.array_equal(again["segmask"], after["segmask"]) and np.array_equal(again["rgb"], after["rgb"])
+
+
+def test_dispatch_constants_follow_the_cu_count(native):
+    # the small-batch BVH thresholds and the "chip is full" workgroup count were
+    # MI355X literals (640 / 1024 views, 1024 workgroups); they are functions of the device's CU
+    # count now -- pure functions, checked here with faked devices
+    lib = native.load_capi()
+    f = lib.mrx_dispatch_min_tris
+    f.restype = ctypes.c_uint32
+    f.argtypes = [ctypes.c_uint32] * 2 + [ctypes.c_int] + [ctypes.c_uint32] * 3
+    g = lib.mrx_group_fill
+    g.restype = ctypes.c_uint32
+    g.argtypes = [ctypes.c_uint32]
+    assert [g(c) for c in (256, 128, 32)] == [1024, 512, 128]
+    for cus in (256, 128, 32):
+        small, mid = cus * 5 // 2, cus * 4
+        # up to 2.5 views per CU: from 65 triangles, textured or not
+        assert f(0, small, 0, 64, 64, cus) == 65 and f(0, small, 1, 64, 64, cus) == 65
+        # up to 4 per CU: from 91, untextured worlds only
+        assert f(0, small + 1, 0, 64, 64, cus) == 91 and f(0, small + 1, 1, 64, 64, cus) == 129
+        assert f(0, mid, 0, 64, 64, cus) == 91 and f(0, mid + 1, 0, 64, 64, cus) == 129
+        # views of several tiles: the general threshold
+        assert f(0, 8, 0, 128, 64, cus) == 129
+        # an explicit threshold is never raised
+        assert f(40, 8, 0, 64, 64, cus) == 40 and f(200, small, 0, 64, 64, cus) == 65
+    # the MI355X values the measurements were taken at (profiles/r03_bvh_threshold.txt)
+    assert f(0, 640, 1, 64, 64, 256) == 65 and f(0, 641, 0, 64, 64, 256) == 91 and f(0, 1025, 0, 64, 64, 256) == 129

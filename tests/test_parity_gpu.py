@@ -791,3 +791,19 @@ def test_raw_c_abi_through_ctypes(native):
     ms = ctypes.c_float()
     assert lib.mrx_time_renders(h, 5, ctypes.byref(ms)) == 0 and ms.value > 0
     lib.mrx_destroy(h)
+
+
+@pytest.mark.parametrize("cus", [32, 128])
+def test_launch_shapes_of_a_smaller_device_render_the_same_pixels(native, monkeypatch, cus):
+    # "does the batch fill the chip" is decided from the device's CU count
+    # (raster.hpp groupFill / bvhDispatchMinTris; mrx_create reads the attribute).  MRX_FAKE_CUS
+    # makes the host choose the shapes a 32- or 128-CU device (a partitioned MI355X) would get:
+    # other workgroup shapes, other dispatch thresholds, the same pixels.
+    from tests import meshes as tmeshes
+    monkeypatch.setenv("MRX_FAKE_CUS", str(cus))
+    for d in (scenes.synthetic_scene(300), scenes.synthetic_scene(130, with_wall=True, textured=True),
+              tmeshes.cube_field(num_worlds=100, cubes=6)):          # 74 triangles: BVH path up to 2.5 views per CU
+        r = make_product(d, visibility=True)
+        if d.instances and len(d.instances) // d.num_worlds == 7:
+            assert r.render_path() == ("bvh" if 2 * 100 <= 5 * cus else "raster")
+        assert_parity(fetch(r), render_oracle(d))

@@ -215,3 +215,55 @@ def test_spawn_crosses_the_kernel_threshold(native):
     r.step()
     assert r.render_path() == "bvh"                       # 19 cubes + plane = 230 triangles
     assert_parity(fetch(r), fs.render())
+
+
+def test_spawned_rows_on_a_renderer_of_three_shards_agree_with_the_float64_ray_caster(native, monkeypatch):
+    # spawned rows and multi-shard renders were checked against the oracle only.
+    # Here the PRODUCT's pixels -- cubes bound at run time into spare rows, on a renderer of three
+    # shards -- are compared with the independent float64 Moeller-Trumbore ray caster and shading
+    # model of tests/test_independent_raycast.py (world-space rays, no edge functions, no S6b, NumPy):
+    # wherever float64 is decisive the product names the same triangle, the same depth to 1e-4 and
+    # the same colour byte.
+    import torch
+    from oracle import oracle
+    from tests.test_independent_raycast import raycast_colour, raycast_view
+    d = scenes.synthetic_scene(20, with_wall=True, textured=True)
+    d.max_instances_per_world = 5
+    monkeypatch.setenv("MADRONA_MI355_VISIBILITY", "1")
+    monkeypatch.setenv("MRX_SHARD_THREADS", "2")
+    r = scenes.make_renderer(d, device_ids=[0, 0, 0])
+    fs = oracle.FlatScene(d)                      # (used as the scene's data container and kept in step by hand)
+    rng = np.random.default_rng(5)
+    spare = np.flatnonzero(fs.inst_obj0 < 0)
+    for w in range(d.num_worlds):
+        lo, hi = fs.world_inst_start[w], fs.world_inst_start[w + 1]
+        for row in spare[(spare >= lo) & (spare < hi)][:2]:
+            fs.inst_obj[row] = 0
+            fs.inst_pos[row] = np.float32(rng.uniform(-3, 3, 3) + np.array([0, 0, 2.0]))
+            fs.inst_scale[row] = np.float32(rng.uniform(0.5, 1.5))
+    for i in range(3):
+        lo, hi = scenes.shard_range(d.num_worlds, i, 3)
+        a, b = int(fs.world_inst_start[lo]), int(fs.world_inst_start[hi])
+        for t, src in ((r.instance_object_tensor(shard=i), fs.inst_obj), (r.instance_position_tensor(shard=i), fs.inst_pos),
+                       (r.instance_scale_tensor(shard=i), fs.inst_scale)):
+            tt = t.to_torch()
+            tt.copy_(torch.from_numpy(np.ascontiguousarray(src[a:b])).to(tt.device))
+    r.refresh_objects()
+    fs.refresh_objects()
+    r.step()
+    got = _shard_outputs(r, 3)
+    checked = spawned_seen = 0
+    for v in (0, 6, 7, 13, 19):                   # views of all three shards (7 + 7 + 6 worlds)
+        tri, depth, margin = raycast_view(fs, v)
+        sure = margin > 1e-5
+        assert np.array_equal(got["ids"][v][sure], tri[sure]), \
+            f"view {v}: {(got['ids'][v][sure] != tri[sure]).sum()} decisive pixels name another triangle"
+        np.testing.assert_allclose(got["depth"][v][sure], depth[sure], rtol=1e-4)
+        rgb, sure_tex = raycast_colour(fs, v)
+        ok = sure & sure_tex & (tri >= 0) & (margin > 1e-4)
+        diff = np.abs(got["rgb"][v][..., :3].astype(np.float64) - np.floor(rgb + 0.5))
+        near_half = np.abs(rgb - np.floor(rgb) - 0.5) < 0.02
+        assert not (ok[..., None] & (diff > np.where(near_half, 1.0, 0.0))).any()
+        checked += int(sure.sum())
+        spawned_seen += int((tri[sure] >= 26).sum())      # cube + plane + wall = 26 triangles: beyond = spawned cubes
+    assert checked > 10000 and spawned_seen > 50
