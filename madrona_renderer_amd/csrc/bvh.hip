@@ -204,6 +204,15 @@ constexpr int tabCap(bool tex, int tw, int th, bool cls) { return tex ? 256 : (t
 constexpr int tabUsable(int cap) { return cap < (int)kStashed ? cap : (int)kStashed; }   // slot kStashed is the marker
 constexpr int bigCap(int tw, int th, bool cls) { return tw * th >= 4096 && cls ? 96 : 64; }   // (>= 64: one batch always fits an empty list)
 
+// Row stride of the tile's depth buffer = tile width + kZPad pixels (8 bytes each).  At a stride of 64 pixels =
+// 128 dwords, rows fall on the same LDS banks: the (triangle, row) items of the small-triangle walk are consecutive
+// rows of one triangle at the same x, lane by lane -- an up to 16-way conflict on every ds_max_u64 -- and the eight
+// rows of a strip pass collide four ways (profiles/r03_bvh482_pmc_sq.txt: conflict replays >= useful LDS cycles).
+#ifndef MRX_BVH_ZPAD
+#define MRX_BVH_ZPAD 1
+#endif
+constexpr int kZPad = MRX_BVH_ZPAD;
+
 struct WaveScratch {
     // (instance of the pass, object triangle)
     uint2 queue[kQueueCap];
@@ -489,6 +498,7 @@ void bvhTileKernel(const RasterParams p)
     // 482-triangle worlds 25.4 -> 26.0 us, textured 35.6 -> 35.4: this kernel's first phase waits for its pose
     // loads and a barrier either way, and the seven dwords cost the untextured instantiation three VGPRs)
     constexpr int kBvhWaves = TH / 8;             // one wave per TW x 8 strip of the tile
+    constexpr int ZS = TW + kZPad;                // row stride of the depth buffer, in pixels (kZPad above)
     constexpr int kHalves = TW / 32;              // 32-pixel halves of a strip: 4 pixels of a lane each
     constexpr int kCap = tabCap(TEX, TW, TH, CLS);
     constexpr uint32_t kUsable = (uint32_t)tabUsable(kCap);      // records a round can hold
@@ -566,7 +576,7 @@ void bvhTileKernel(const RasterParams p)
     // ---- LDS: depth buffer of the tile, shading records of the pass, control
     //      words, the TLAS of the pass, per-wave scratch
     unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [TH][TW]
-    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + TW * TH);                         // [kCap] rgba tex obj k
+    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + ZS * TH);                         // [kCap] rgba tex obj k
     float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [16]: counters, [8..10] light direction
     float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 16);                  // [kBigCap] planes, key, box
@@ -611,10 +621,10 @@ void bvhTileKernel(const RasterParams p)
                                   : (i1 > i0 ? min(passInst, i1 - i0) : 0u);
         const uint32_t busy = min(((n0 + kWave - 1u) / kWave) << vShift, (uint32_t)kBvhWaves);
         if (busy >= (uint32_t)kBvhWaves) {
-            for (int i = threadIdx.x; i < TW * TH; i += kWave * kBvhWaves)
+            for (int i = threadIdx.x; i < ZS * TH; i += kWave * kBvhWaves)
                 zbuf[i] = packHit(invFar, 0u);
         } else if ((uint32_t)wave >= busy) {
-            for (uint32_t i = ((uint32_t)wave - busy) * kWave + (uint32_t)lane; i < (uint32_t)(TW * TH);
+            for (uint32_t i = ((uint32_t)wave - busy) * kWave + (uint32_t)lane; i < (uint32_t)(ZS * TH);
                  i += ((uint32_t)kBvhWaves - busy) * kWave)
                 zbuf[i] = packHit(invFar, 0u);
         }
@@ -942,7 +952,7 @@ void bvhTileKernel(const RasterParams p)
                             const f32x2 yy = { py, py };
                             const f32x2 r01 = fma2(B01, yy, C01);
                             const f32x2 r2d = fma2(B2D, yy, C2D);
-                            unsigned long long *zline = zbuf + (sy - (int)tileY0) * TW - (int)tileX0;
+                            unsigned long long *zline = zbuf + (sy - (int)tileY0) * ZS - (int)tileX0;
                             for (int sx = xBeg; __ballot(act && sx < xEnd) != 0; sx += 4) {
                                 if (act && sx < xEnd) {
 #pragma unroll
@@ -1115,7 +1125,7 @@ void bvhTileKernel(const RasterParams p)
                         // and two selects per test to imitate
                         const float py = (float)(tileY0 + 8u * wave + ly);
                         const f32x2 yy = { py, py };
-                        unsigned long long *zrow = zbuf + (8 * wave + ly) * TW + 32 * hf + 4 * lx;
+                        unsigned long long *zrow = zbuf + (8 * wave + ly) * ZS + 32 * hf + 4 * lx;
                         for (; act != 0; act &= act - 1) {
                             const int l = (int)e0 + __builtin_ctzll(act);
                             const PlanePairs q = loadPlanes(bigList, l);
@@ -1147,7 +1157,7 @@ void bvhTileKernel(const RasterParams p)
                 KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(pk));
                 const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
-                resolveStrip<IDS, TEX, TW, TH, false>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
+                resolveStrip<IDS, TEX, TW, TH, false, ZS>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
             }
             if (!(dskip & 128u)) MRX_STAMP(5);
             if (allDone) {
@@ -1165,7 +1175,7 @@ void bvhTileKernel(const RasterParams p)
             KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pk));
             const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
-            resolveStrip<IDS, TEX, TW, TH, true>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
+            resolveStrip<IDS, TEX, TW, TH, true, ZS>(ra, zbuf, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
         }
         if (--left == 0)
             break;
@@ -1173,8 +1183,8 @@ void bvhTileKernel(const RasterParams p)
         //      touches it between the barrier ahead of the large pass and the one below), the rectangle
         //      moves on, the traversal state starts over; the TLAS, the view constants and the light
         //      direction stay.  One barrier: every strip is clear before anyone merges into it.
-        for (int i = lane; i < TW * 8; i += kWave)
-            zbuf[8 * wave * TW + i] = packHit(invFar, 0u);
+        for (int i = lane; i < ZS * 8; i += kWave)
+            zbuf[8 * wave * ZS + i] = packHit(invFar, 0u);
         if (MULTI) {
             // the next view of the group: its TLAS is the next block
             ++view;
@@ -1547,7 +1557,7 @@ std::mutex attrMutex;
 size_t ldsFor(uint32_t passInst, bool textured, int tw, int th, bool cls, uint32_t tlasBlocks)
 {
     const size_t cap = (size_t)tabCap(textured, tw, th, cls);
-    return (size_t)tw * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th, cls) * 64 +
+    return (size_t)(tw + kZPad) * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th, cls) * 64 +
            ((size_t)passInst * (kInstRecDw + 4) * 4 + 16) * tlasBlocks + sizeof(WaveScratch) * (size_t)(th / 8);
 }
 }  // namespace
