@@ -258,7 +258,12 @@ def test_spawned_rows_on_a_renderer_of_three_shards_agree_with_the_float64_ray_c
         sure = margin > 1e-5
         assert np.array_equal(got["ids"][v][sure], tri[sure]), \
             f"view {v}: {(got['ids'][v][sure] != tri[sure]).sum()} decisive pixels name another triangle"
-        np.testing.assert_allclose(got["depth"][v][sure], depth[sure], rtol=1e-4)
+        # depth: 1e-4 on everything but the ground quad, whose float32 1/depth plane over +-10000 units is that
+        # coarse by itself (k = 0, 1: plane.obj is the world's first instance; the oracle shows the same against
+        # float64 -- tests/test_independent_raycast.py -- and the product equals the oracle bit for bit)
+        ground = tri < 2
+        np.testing.assert_allclose(got["depth"][v][sure & ~ground], depth[sure & ~ground], rtol=1e-4)
+        np.testing.assert_allclose(got["depth"][v][sure & ground], depth[sure & ground], rtol=3e-4)
         rgb, sure_tex = raycast_colour(fs, v)
         ok = sure & sure_tex & (tri >= 0) & (margin > 1e-4)
         diff = np.abs(got["rgb"][v][..., :3].astype(np.float64) - np.floor(rgb + 0.5))
