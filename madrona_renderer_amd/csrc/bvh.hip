@@ -200,9 +200,19 @@ constexpr uint32_t kStashed = (1u << kSlotBits) - 1u;
 // (64x64 tiles, untextured: 768 records and 64 list entries cost cube fields of up to 4994 triangles nothing against
 // 1024 and 96 -- profiles/r03_bvh_priority.txt -- and leave room for two TLAS blocks of 104 instances beside two
 // workgroups per CU; worlds of BLAS meshes, the CLS instantiations, lose 16 % with them and keep the larger ones)
-constexpr int tabCap(bool tex, int tw, int th, bool cls) { return tex ? 256 : (tw * th >= 4096 ? (cls ? 1024 : 768) : 512); }
+// Textured instantiations (round 4): ONE table of 48-byte records -- u/v planes (or, for an untextured triangle of a
+// textured scene, the packed colour), lit colour, texel offset, width | height << 16 (0 = untextured), object id --
+// instead of a 16-byte record plus a 48-byte one, and as many of them as the launch's LDS has room for (p.bvhTexCap, chosen
+// by the host: 256 records now take 12 KB, which lets worlds of up to 104 instances render two views per workgroup; worlds
+// that do not get pairs take up to 512).  A round that fills the table stashes its winners and starts over, so every
+// record more is a later round boundary (profiles/r04_bvh_textured.txt).
+#ifndef MRX_TEX_BIGCAP
+#define MRX_TEX_BIGCAP 64
+#endif
+constexpr int tabCap(bool tex, int tw, int th, bool cls) { return tex ? 0 : (tw * th >= 4096 ? (cls ? 1024 : 768) : 512); }
+constexpr size_t tabBytes(bool tex, int cap) { return tex ? (size_t)cap * 48u : (size_t)cap * 16u; }
 constexpr int tabUsable(int cap) { return cap < (int)kStashed ? cap : (int)kStashed; }   // slot kStashed is the marker
-constexpr int bigCap(int tw, int th, bool cls) { return tw * th >= 4096 && cls ? 96 : 64; }   // (>= 64: one batch always fits an empty list)
+constexpr int bigCap(int tw, int th, bool cls, bool tex = false) { return tw * th >= 4096 && cls ? 96 : (tex ? MRX_TEX_BIGCAP : 64); }   // (>= 64: one batch always fits an empty list)
 
 // Row stride of the tile's depth buffer = tile width + kZPad pixels (8 bytes each).  At a stride of 64 pixels =
 // 128 dwords, rows fall on the same LDS banks: the (triangle, row) items of the small-triangle walk are consecutive
@@ -212,6 +222,13 @@ constexpr int bigCap(int tw, int th, bool cls) { return tw * th >= 4096 && cls ?
 #define MRX_BVH_ZPAD 1
 #endif
 constexpr int kZPad = MRX_BVH_ZPAD;
+
+// width | height << 16 of a texture descriptor (offset, width, height) as the unified record holds it;
+// the host refuses textures beyond 65535 texels a side
+__device__ __forceinline__ float packTexDims(float4 texDesc)
+{
+    return __uint_as_float((__float_as_uint(texDesc.y) & 0xFFFFu) | (__float_as_uint(texDesc.z) << 16));
+}
 
 struct WaveScratch {
     // (instance of the pass, object triangle)
@@ -300,10 +317,20 @@ __device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long 
             // its winners marked, and slots are handed out before any pixel is written
             mine[b] = low[b] != 0u && slot != kStashed;
             anyStashed = anyStashed || (low[b] != 0u && slot == kStashed);
-            const float4 rec = shadeTab[mine[b] ? slot : 0u];
-            rgba[b] = mine[b] ? __float_as_uint(rec.x) : 0xFF000000u;
-            seg[b] = mine[b] ? __float_as_int(rec.z) : -1;
-            texOn[b] = TEX && mine[b] && __float_as_int(rec.y) >= 0;
+            if (TEX) {
+                // the unified record: [0] packed colour of an untextured triangle, [8..11] = lit.b, texel offset,
+                // width | height << 16 (0: untextured), object id
+                const float *recT = coldTab[mine[b] ? slot : 0u];
+                const float4 tail = reinterpret_cast<const float4 *>(recT)[2];
+                rgba[b] = mine[b] ? __float_as_uint(recT[0]) : 0xFF000000u;
+                seg[b] = mine[b] ? __float_as_int(tail.w) : -1;
+                texOn[b] = mine[b] && __float_as_uint(tail.z) != 0u;
+            } else {
+                const float4 rec = shadeTab[mine[b] ? slot : 0u];
+                rgba[b] = mine[b] ? __float_as_uint(rec.x) : 0xFF000000u;
+                seg[b] = mine[b] ? __float_as_int(rec.z) : -1;
+                texOn[b] = false;
+            }
             texSlot[b] = texOn[b] ? slot : 0u;
             anyTexOn = anyTexOn || texOn[b];
         }
@@ -321,7 +348,7 @@ __device__ __forceinline__ void resolveStrip(const ResolveArgs p, unsigned long 
                 const float tt = 1.0f / it;
                 const float u = __builtin_fmaf(cold[0], px, __builtin_fmaf(cold[1], py, cold[2])) * tt;
                 const float v = __builtin_fmaf(cold[3], px, __builtin_fmaf(cold[4], py, cold[5])) * tt;
-                const int tw = __float_as_int(cold[10]), th = __float_as_int(cold[11]);
+                const int tw = (int)(__float_as_uint(cold[10]) & 0xFFFFu), th = (int)(__float_as_uint(cold[10]) >> 16);
                 const float uf = u - floorf(u);
                 float vf = v - floorf(v);
                 vf = 1.0f - vf;
@@ -500,10 +527,13 @@ void bvhTileKernel(const RasterParams p)
     constexpr int kBvhWaves = TH / 8;             // one wave per TW x 8 strip of the tile
     constexpr int ZS = TW + kZPad;                // row stride of the depth buffer, in pixels (kZPad above)
     constexpr int kHalves = TW / 32;              // 32-pixel halves of a strip: 4 pixels of a lane each
-    constexpr int kCap = tabCap(TEX, TW, TH, CLS);
-    constexpr uint32_t kUsable = (uint32_t)tabUsable(kCap);      // records a round can hold
+    // records a round can hold: a constant of the untextured instantiations; the textured ones take it from the host
+    // (p.bvhTexCap: as many 48-byte records as fit beside the launch's TLAS blocks, mrx_api.cpp chooseBvhGroups)
+    constexpr int kCapC = tabCap(false, TW, TH, CLS);
+    const uint32_t kCap = TEX ? p.bvhTexCap : (uint32_t)kCapC;
+    const uint32_t kUsable = TEX ? min(kCap, kStashed) : (uint32_t)tabUsable(kCapC);
     constexpr bool kPartial = TEX || CLS;
-    constexpr int kBigCap = bigCap(TW, TH, CLS);
+    constexpr int kBigCap = bigCap(TW, TH, CLS, TEX);
     static_assert((TW == 64 || TW == 32) && (TH == 64 || TH == 32), "tile shapes of the sweep");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x % kWave;
@@ -576,9 +606,11 @@ void bvhTileKernel(const RasterParams p)
     // ---- LDS: depth buffer of the tile, shading records of the pass, control
     //      words, the TLAS of the pass, per-wave scratch
     unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);           // [TH][TW]
-    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + ZS * TH);                         // [kCap] rgba tex obj k
-    float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kCap);      // [kCap] (TEX)
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(coldTab + (TEX ? kCap : 0));         // [16]: counters, [8..10] light direction
+    // the record table: [kCap] float4 (rgba, texture, object id, k) -- or, TEX, [kCap][12] unified records (tabCap above)
+    float4 *shadeTab = reinterpret_cast<float4 *>(zbuf + ZS * TH);
+    float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab);
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(shadeTab) +
+                                                  (TEX ? (size_t)kCap * 48u : (size_t)kCapC * 16u));   // [16]: counters
     float (*bigList)[16] = reinterpret_cast<float (*)[16]>(ctrl + 16);                  // [kBigCap] planes, key, box
     WaveScratch *ws = reinterpret_cast<WaveScratch *>(bigList + kBigCap) + wave;      // (fixed offsets first)
     // the TLAS of a view: the light direction in the view's frame and the number of instances (four
@@ -882,7 +914,14 @@ void bvhTileKernel(const RasterParams p)
                 const uint32_t slot = slotBase + liveRank;
                 const uint32_t lowKey = ((~kTri & kKeyMask) << kSlotBits) | slot;
                 if (live) {
-                    shadeTab[slot] = make_float4(shade[0], shade[1], shade[2], __uint_as_float(kTri));   // [2]: the triangle's object id
+                    if (!TEX)
+                        shadeTab[slot] = make_float4(shade[0], shade[1], shade[2], __uint_as_float(kTri));   // [2]: the triangle's object id
+                    else if (__float_as_int(shade[1]) < 0) {
+                        // an untextured triangle of a textured scene: packed colour, "no texture", object id
+                        float *dst = coldTab[slot];
+                        dst[0] = shade[0];
+                        *reinterpret_cast<float2 *>(dst + 10) = make_float2(__uint_as_float(0u), shade[2]);
+                    }
                     if (TEX && __float_as_int(shade[1]) >= 0) {
                         // the u/v planes from the edge planes, the texture coordinates (read again:
                         // L1 / L2 hits) and |1/d|; the texture's descriptor rides with the material
@@ -897,7 +936,7 @@ void bvhTileKernel(const RasterParams p)
                         float4 *cdst = reinterpret_cast<float4 *>(coldTab[slot]);
                         cdst[0] = make_float4(uvp[0], uvp[1], uvp[2], uvp[3]);
                         cdst[1] = make_float4(uvp[4], uvp[5], cold[6], cold[7]);
-                        cdst[2] = make_float4(cold[8], texDesc.x, texDesc.y, texDesc.z);
+                        cdst[2] = make_float4(cold[8], texDesc.x, packTexDims(texDesc), shade[2]);
                     }
                 }
                 if (dskip & 128u) MRX_STAMP(3);
@@ -1263,7 +1302,7 @@ constexpr int kFlatZS = MRX_FLAT_ZS;
 constexpr size_t kFlatZBytes = 2u * 64u * kFlatZS * 8u;
 constexpr size_t flatLdsBytes(bool tex)
 {
-    return kFlatZBytes + kFlatTris * 64u + (kFlatTris + 2u) * 16u + (tex ? (kFlatTris + 2u) * kCold * 4u : 0u) + 16u +
+    return kFlatZBytes + kFlatTris * 64u + tabBytes(tex, kFlatTris + 2) + 16u +
            (size_t)kFlatTris * kInstRecDw * 4u;
 }
 
@@ -1289,9 +1328,9 @@ void bvhFlatKernel(const RasterParams p)
 
     unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(smem);                   // [2][TH][TW]
     float (*triRec)[16] = reinterpret_cast<float (*)[16]>(smem + kFlatZBytes);                 // [64] planes, box
-    float4 *shadeTab = reinterpret_cast<float4 *>(triRec + kFlatTris);                          // [66]: slot k + 1
-    float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab + kFlatTris + 2);     // [66] (TEX)
-    float *hdr = reinterpret_cast<float *>(coldTab + (TEX ? kFlatTris + 2 : 0));                // light direction
+    float4 *shadeTab = reinterpret_cast<float4 *>(triRec + kFlatTris);                          // [66]: slot k + 1 (TEX: the
+    float (*coldTab)[kCold] = reinterpret_cast<float (*)[kCold]>(shadeTab);                     // unified 48-byte records)
+    float *hdr = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(shadeTab) + tabBytes(TEX, kFlatTris + 2));
     float *instRec = hdr + 4;                                                                    // [64][24]
 
     unsigned long long *stamps = (MRX_BVH_DIAG && p.debugStamps && wave < 4)
@@ -1365,7 +1404,13 @@ void bvhFlatKernel(const RasterParams p)
             const int32_t objL = __float_as_int(a4.w);
             float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
             valid = setupTriangleCore<false>(p, vc.lv, y, myTri, objL, (int32_t)lane, c, shade, cold);
-            shadeTab[lane + 1] = make_float4(shade[0], shade[1], shade[2], __int_as_float(lane));
+            if (!TEX)
+                shadeTab[lane + 1] = make_float4(shade[0], shade[1], shade[2], __int_as_float(lane));
+            else if (!(valid && __float_as_int(shade[1]) >= 0)) {
+                float *dst = coldTab[lane + 1];
+                dst[0] = shade[0];
+                *reinterpret_cast<float2 *>(dst + 10) = make_float2(__uint_as_float(0u), shade[2]);
+            }
             if (TEX && valid && __float_as_int(shade[1]) >= 0) {
                 // (u/v planes as the general kernel derives them: uvPlanes() from the edge planes and |1/d|)
                 const float4 *tsrc = reinterpret_cast<const float4 *>(p.tris + myTri);
@@ -1377,7 +1422,7 @@ void bvhFlatKernel(const RasterParams p)
                 float4 *cdst = reinterpret_cast<float4 *>(coldTab[lane + 1]);
                 cdst[0] = make_float4(uvp[0], uvp[1], uvp[2], uvp[3]);
                 cdst[1] = make_float4(uvp[4], uvp[5], cold[6], cold[7]);
-                cdst[2] = make_float4(cold[8], texDesc.x, texDesc.y, texDesc.z);
+                cdst[2] = make_float4(cold[8], texDesc.x, packTexDims(texDesc), shade[2]);
             }
         }
         {
@@ -1554,17 +1599,17 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex attrMutex;
 // LDS bytes of one workgroup for a tile shape
-size_t ldsFor(uint32_t passInst, bool textured, int tw, int th, bool cls, uint32_t tlasBlocks)
+size_t ldsFor(uint32_t passInst, bool textured, int tw, int th, bool cls, uint32_t tlasBlocks, uint32_t texCap)
 {
-    const size_t cap = (size_t)tabCap(textured, tw, th, cls);
-    return (size_t)(tw + kZPad) * th * 8 + cap * 16 + (textured ? cap * kCold * 4 : 0) + 64 + (size_t)bigCap(tw, th, cls) * 64 +
+    const size_t cap = textured ? (size_t)texCap : (size_t)tabCap(false, tw, th, cls);
+    return (size_t)(tw + kZPad) * th * 8 + tabBytes(textured, (int)cap) + 64 + (size_t)bigCap(tw, th, cls, textured) * 64 +
            ((size_t)passInst * (kInstRecDw + 4) * 4 + 16) * tlasBlocks + sizeof(WaveScratch) * (size_t)(th / 8);
 }
 }  // namespace
 
-size_t bvhLdsBytes(uint32_t passInst, bool textured, bool classify, uint32_t groupViews)
+size_t bvhLdsBytes(uint32_t passInst, bool textured, bool classify, uint32_t groupViews, uint32_t texCap)
 {
-    return ldsFor(passInst, textured, 64, 64, classify, groupViews);
+    return ldsFor(passInst, textured, 64, 64, classify, groupViews, texCap);
 }
 
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
@@ -1625,7 +1670,9 @@ hipError_t launchBvh(const RasterParams &p, hipStream_t stream)
         if (resident >= items && resident <= p.numViews)
             items = resident;
     }
-    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th, p.bvhTile == 0 && p.bvhClassify, groupViews);
+    if (tex && (p.bvhTexCap < 64u || p.bvhTexCap > 1023u))
+        return hipErrorInvalidValue;
+    const size_t lds = ldsFor(p.bvhPassInst, tex, tw, th, p.bvhTile == 0 && p.bvhClassify, groupViews, p.bvhTexCap);
     const dim3 grid(items), block(kWave * (th / 8));
     // The kernel needs more dynamic LDS than the 64 KB a launch may ask for by default.  The
     // opt-in is a property of (function, device) -- a renderer per device in one process

@@ -729,7 +729,8 @@ int chooseBvhGroups(mrx_renderer &r)
         const bool mixed = nviews > resident && nviews <= 2u * resident &&
                            (maxWorldInst <= 64u || 2u * nviews >= 3u * resident);
         const bool pairsPay = mixed || nviews >= 4u * resident;
-        p.bvhGroupViews = pairsPay && bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u) <= 80u * 1024u ? 2u : 1u;
+        // (textured: pairs as long as two TLAS blocks leave room for 256 records)
+        p.bvhGroupViews = pairsPay && bvhLdsBytes(p.bvhPassInst, tex, p.bvhClassify != 0, 2u, 256u) <= 80u * 1024u ? 2u : 1u;
         if (p.bvhGroupViews == 2u && mixed && !std::getenv("MRX_BVH_NO_MIXED"))
             p.bvhGroupViews |= 0x10000u;
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_VIEWS")) {
@@ -753,6 +754,17 @@ int chooseBvhGroups(mrx_renderer &r)
     const uint32_t gv = p.bvhGroupViews & 0xFFFFu;
     const uint32_t wgs = (p.bvhGroupViews & 0x10000u) ? resident
                          : gv > 1 ? (nviews + gv - 1) / gv : nviews * ((tiles + groupTiles - 1) / groupTiles);
+    // textured worlds: as many 48-byte shading records per round as fit the half CU beside the TLAS block(s), in 32s
+    // (profiles/r04_bvh_textured.txt; MRX_BVH_TEX_CAP overrides)
+    {
+        uint32_t cap = 64;
+        while (cap + 32u <= 1008u &&
+               bvhLdsBytes(p.bvhPassInst, true, p.bvhClassify != 0, gv, cap + 32u) <= 80u * 1024u)
+            cap += 32u;
+        if (const char *dbg = std::getenv("MRX_BVH_TEX_CAP"))
+            cap = (uint32_t)std::max(64, std::min((int)cap, std::atoi(dbg)));
+        p.bvhTexCap = cap;
+    }
     p.bvhGroupViews |= std::min(resident / 2u, 4095u) << 20;      // (the first index of a CU's second workgroup)
     if (prio && p.bvhTile == 0 && tiles == 1 && wgs <= resident && wgs > resident / 2u)
         p.bvhGroupViews |= (uint32_t)prio << 17;
@@ -995,6 +1007,10 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         std::string err;
         if (!decodeTexture(cfg.texture_paths[t], img, err))
             return fail(MRX_E_ASSET, "Failed to load texture: " + err);
+        // (the BVH kernels' shading records hold width | height << 16)
+        if (img.width == 0 || img.height == 0 || img.width > 65535u || img.height > 65535u)
+            return fail(MRX_E_UNSUPPORTED, std::string("texture ") + cfg.texture_paths[t] +
+                                               ": sides of 1 ... 65535 texels are supported");
         TexDesc d {};
         d.offset = (uint32_t)texels.size();
         d.width = img.width;
@@ -1021,7 +1037,8 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
             if (found < 0) {
                 Image img;
                 std::string terr;
-                if (decodeTexture(fm.mapKd, img, terr)) {
+                if (decodeTexture(fm.mapKd, img, terr) && img.width >= 1 && img.height >= 1 && img.width <= 65535u &&
+                    img.height <= 65535u) {
                     TexDesc d {};
                     d.offset = (uint32_t)texels.size();
                     d.width = img.width;

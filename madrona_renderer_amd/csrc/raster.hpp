@@ -157,6 +157,9 @@ struct RasterParams {
     // every world holds at most 64 triangles in at most 64 instance rows: the kernel that sets a view's
     // triangles up once and shares the per-tile work among all waves (bvh.hip, bvhFlatKernel; MRX_BVH_FLAT=0: never)
     uint32_t bvhFlat;
+    // textured BVH instantiations: 48-byte shading records per round of a tile (64 ... 1023; chosen by the host so that
+    // the workgroup's LDS stays within half a CU's: mrx_api.cpp chooseBvhGroups)
+    uint32_t bvhTexCap;
     // compute units of the device the renderer runs on (hipDeviceAttributeMultiprocessorCount at creation):
     // every "does the batch fill the chip" decision of the launchers follows from it (groupFill below)
     uint32_t numCUs;
@@ -249,6 +252,6 @@ hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
 hipError_t launchBvh(const RasterParams &p, hipStream_t stream);
 constexpr uint32_t kBvhMaxWorldTris = 0x1FFFFEu;   // the depth buffer's key holds 21 bits of triangle index
 // dynamic LDS bytes one workgroup of the BVH kernel needs for `passInst` instance records
-size_t bvhLdsBytes(uint32_t passInst, bool textured, bool classify, uint32_t groupViews);
+size_t bvhLdsBytes(uint32_t passInst, bool textured, bool classify, uint32_t groupViews, uint32_t texCap);
 
 }  // namespace mrx
