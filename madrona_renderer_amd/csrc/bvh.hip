@@ -1285,6 +1285,10 @@ void bvhTileKernel(const RasterParams p)
 //                   i + 1: one barrier per tile instead of two.
 // The pixel test, the (1/depth, lower index) order and the records are those of the general
 // kernel, so the output is the same bit for bit.  MRX_BVH_FLAT=0 keeps such worlds on it.
+// (Measured and not kept, profiles/r04_flat_whole_ab.txt: large triangles that cover a 32x8 half entirely --
+// all three edge planes >= 0 at the least favourable corner, the ground quad on most tiles -- walked with the
+// 1/depth plane alone: configs[4] 519.4 -> 516.2 us, one-tile views 1.3 % slower.  The vector instructions of
+// the large pass are not what a tile waits for.)
 // ---------------------------------------------------------------------------
 constexpr int kFlatTris = 64;                      // triangles and instance rows per world, at most
 // Row stride of the flat kernel's depth buffers, in pixels: 64 + 1.  A lane of a strip pass owns pixels
