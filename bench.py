@@ -84,6 +84,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary 1024-world measurement")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the BASELINE configs[2] / configs[4] entries (`also_configs`)")
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the configs[3] strong-scaling measurement")
     ap.add_argument("--strong-worlds", type=int, default=STRONG_WORLDS,
@@ -537,6 +539,37 @@ def run_rank(a):
                            "roofline": bvh_roofline("1024x64x64+cubes40", ms4 * 1000.0 / a.steps, 1024, 1),
                            "settle_s": 0.1, "settle_renders": settle4}
         del r4
+
+    if n_gpus == 1 and not a.no_extra and not a.no_configs and a.variant == 0 and not a.cubes:
+        # BASELINE.json configs[2] and configs[4] at their full size, so that the driver's own run carries them:
+        # 4096 x 128x128 cube+plane+wall (tiled raster), 4096 x 256x256 Raytracer textured cube+plane through the
+        # default dispatch (tiled raster kernel) and through the BVH ray-trace path the config names (kernel_variant
+        # 2: bvhFlatKernel).  Outputs of 0.5 - 3 GiB: `placement` says which mode the allocation got.
+        entries = []
+        for label, kw, variant, k in (
+                ("configs[2]: 4096 worlds x 128x128 cube+plane+wall, tiled raster",
+                 dict(width=128, height=128, with_wall=True), 0, 300),
+                ("configs[4]: 4096 worlds x 256x256 Raytracer, textured cube+plane, default dispatch (tiled raster kernel)",
+                 dict(width=256, height=256, textured=True, render_mode="Raytracer"), 0, 60),
+                ("configs[4] through the BVH ray-trace path (kernel_variant 2)",
+                 dict(width=256, height=256, textured=True, render_mode="Raytracer"), 2, 60)):
+            if variant:
+                os.environ["MADRONA_MI355_KERNEL"] = str(variant)
+            try:
+                rc = scenes.make_renderer(scenes.synthetic_scene(4096, **kw), gpu_id=local)
+            finally:
+                os.environ.pop("MADRONA_MI355_KERNEL", None)
+            k = min(k, max(a.steps, 20))
+            settle(rc, 0.1)
+            wc, msc = timed_steps(rc, k, lambda: None)
+            bc = int(rc.bytes_per_step())
+            entries.append({"workload": label, "render_path": rc.render_path(), "steps": k,
+                            "value": 4096 * k / wc, "unit": "views/s", "ms_per_step": wc * 1000.0 / k,
+                            "kernel_us": msc * 1000.0 / k, "bytes_per_launch": bc,
+                            "frac_kernel": bc / (msc * 1e-3 / k) / 1e9 / HBM_PEAK_GBPS,
+                            "placement": rc.placement()})
+            del rc
+        out["also_configs"] = entries
 
     if not a.no_strong:
         # BASELINE.json configs[3]: 16384 worlds x 64x64 cube+plane IN TOTAL, world-sharded:

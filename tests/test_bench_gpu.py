@@ -64,6 +64,15 @@ def test_bench_extras_configs1_and_the_bvh_path(native):
     assert abs(bv["roofline"]["peak"] - 1228.8) < 1e-6 and isinstance(bv["roofline"]["stale"], bool)
     lp = out["also_loop"]
     assert lp["ms_per_iteration"] > lp["ms_update_alone"] > 0 and lp["iterations"] == 100
+    # BASELINE configs[2] and configs[4] (default dispatch and the BVH path the config names) at full size
+    cf = out["also_configs"]
+    assert [c["render_path"] for c in cf] == ["raster", "raster", "bvh"]
+    assert cf[0]["bytes_per_launch"] == 4096 * (128 * 128 * 8 + 3 * 44 + 28)
+    assert cf[1]["bytes_per_launch"] == cf[2]["bytes_per_launch"] == 4096 * (256 * 256 * 12 + 2 * 44 + 28)
+    for c in cf:
+        assert 0.3 < c["frac_kernel"] < 1.0 and c["kernel_us"] > 0 and c["placement"]["tries"] >= 1, c
+    # (round 3: 845 us through the BVH path; the flat kernel: 520 - 650 by placement mode)
+    assert cf[2]["kernel_us"] < 760.0
 
 
 @pytest.mark.gpu
