@@ -132,3 +132,41 @@ def test_mrx_info_keeps_the_abi2_size_and_the_sized_call_gives_the_rest(native):
 def test_more_devices_than_worlds_is_refused(native):
     with pytest.raises(RuntimeError, match="more devices"):
         scenes.make_renderer(scenes.synthetic_scene(2), device_ids=[0, 0, 0])
+
+
+def test_shard_threads_survive_bursts_idle_gaps_and_interleaved_calls(native, monkeypatch):
+    # the shard workers spin for MRX_SHARD_SPIN_US after a command and then sleep in a futex: bursts of
+    # steps, gaps longer than the spin (so that every wake-up path is taken), syncs, timed renders and
+    # pose writes in between, with a short spin and with none -- the pictures stay those of one renderer
+    import time
+    import torch
+    desc = scenes.synthetic_scene(257)
+    for spin in ("50", "0"):
+        monkeypatch.setenv("MRX_SHARD_THREADS", "2")
+        monkeypatch.setenv("MRX_SHARD_SPIN_US", spin)
+        many = scenes.make_renderer(desc, device_ids=[0] * 5)
+        one = scenes.make_renderer(desc)
+        streams = [torch.cuda.Stream() for _ in range(5)]
+        for i, s in enumerate(streams):
+            many.set_stream(s.cuda_stream, shard=i)
+        rng = np.random.default_rng(int(spin) + 1)
+        pos1 = one.instance_position_tensor().to_torch()
+        for burst in range(60):
+            dz = float(np.float32(rng.uniform(-0.05, 0.05)))
+            for i in range(5):
+                with torch.cuda.stream(streams[i]):
+                    many.instance_position_tensor(shard=i).to_torch()[1::2, 2] += dz
+            pos1[1::2, 2] += dz
+            for _ in range(int(rng.integers(1, 40))):
+                many.step()
+            one.step()
+            if burst % 7 == 0:
+                many.sync()
+                time.sleep(0.002)                    # longer than any spin: the workers go to sleep
+            if burst % 11 == 0:
+                assert many.time_renders(5) > 0
+        got = _slabs(many, 5, False)
+        one.sync()
+        assert torch.equal(torch.cat(got["rgb"]), one.rgb_tensor().to_torch())
+        assert torch.equal(torch.cat(got["depth"]).view(torch.int32), one.depth_tensor().to_torch().view(torch.int32))
+        del many, one
