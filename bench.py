@@ -103,6 +103,9 @@ def launch_ranks(n, argv):
     the renderer and makes no HIP call: the ranks are ordinary child processes
     started before anything here could have initialised a GPU.  A rank that fails
     ends the job: the others are stopped (by PID) and its code is returned."""
+    # (the port is free when asked for and handed to the ranks after the probe socket is closed: a process that
+    # grabs it in between makes rank 0's rendezvous fail, the job then ends with that rank's error -- the driver's
+    # own launcher, torch.distributed.run with an explicit --master-port, has the same window; ADVICE r3)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
