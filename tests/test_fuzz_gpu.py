@@ -151,3 +151,21 @@ def test_mesh_worlds_seen_by_random_cameras(native, monkeypatch, seed, size, mod
     ref = render_oracle(d)
     assert_parity(fetch(r), ref)
     assert (ref["tri_id"] >= 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("seed,size,mode", [(41, (64, 64), "Rasterizer"), (44, (64, 64), "Raytracer"),
+                                            (56, (200, 136), "Rasterizer"), (63, (160, 160), "Raytracer")])
+@pytest.mark.parametrize("flat", ["0", "1"], ids=["general-kernel", "flat-kernel"])
+def test_small_worlds_through_both_bvh_kernels(native, monkeypatch, seed, size, mode, flat):
+    # worlds of at most 64 triangles take bvhFlatKernel on the BVH path since round 4 (one set-up per view,
+    # DESIGN.md 4.2b); MRX_BVH_FLAT=0 keeps them on bvhTileKernel.  Both must equal the oracle -- and each other --
+    # on the triangle soups above (multi-camera worlds, empty worlds, eye-plane crossings, ties), and on the
+    # BASELINE textured Raytracer shape at a size the oracle renders in a second.
+    monkeypatch.setenv("MRX_BVH_FLAT", flat)
+    d = _scene(seed, num_worlds=24, width=size[0], height=size[1], mode=mode)
+    r = make_product(d, visibility=True, variant=2)
+    assert r.render_path() == "bvh"
+    assert_parity(fetch(r), render_oracle(d))
+    d5 = scenes.synthetic_scene(40, width=256, height=256, textured=True, render_mode="Raytracer")
+    r5 = make_product(d5, visibility=False, variant=2)
+    assert_parity(fetch(r5, visibility=False, raytracer=True), render_oracle(d5))
