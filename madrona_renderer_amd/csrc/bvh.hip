@@ -1272,9 +1272,13 @@ void bvhTileKernel(const RasterParams p)
 //                   lane = world-local triangle k -> S3-S7 set-up (setupTriangleCore, the same
 //                   call), planes + box into triRec[k], the shading record into slot k + 1 -- the
 //                   record table is the world, nothing is allocated and nothing can overflow.
-//   per tile        every wave classifies the 64 triangles against the tile on its own (lane =
-//                   triangle: box, then the planes at the tile's corner pixels, exact by
-//                   monotonicity), all eight reach the same masks and prefix sums without talking;
+//   once per view   (cont.) every lane keeps its triangle's planes in registers for the whole view, and the
+//                   classification of the 64 triangles against EVERY tile of the group (box, then the planes at
+//                   the tile's corner pixels, exact by monotonicity) is worked out once, wave w for tiles w, w + 8:
+//                   a dword per (tile, triangle) in the LDS the TLAS records occupied (configs[4] 521 -> 496 us;
+//                   before, every wave repeated ~70 dependent vector instructions at the head of every tile)
+//   per tile        every wave reads the tile's 64 dwords, so all eight hold the same masks and prefix sums
+//                   without talking;
 //                   the (triangle, row) items of the small triangles are dealt 64 at a time round
 //                   robin over the WAVES (the general kernel walks a batch in the wave that set it
 //                   up); large triangles are rasterised by every wave over its own strip straight
@@ -1446,22 +1450,26 @@ void bvhFlatKernel(const RasterParams p)
     const int lx = lane & 7, ly = lane >> 3;
     const int smallArea = p.bvhSmallArea;
     const uint32_t lowKey = ((~(uint32_t)lane & kKeyMask) << kSlotBits) | ((uint32_t)lane + 1u);
-    uint32_t buf = 0;
-    for (;;) {
-        const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
-        const float TX0 = (float)tileX0, TX1 = (float)(tileX0 + TW - 1);
-        const float TY0 = (float)tileY0, TY1 = (float)(tileY0 + TH - 1);
-        unsigned long long *zb = zbuf + (size_t)buf * (kFlatZS * TH);
-        // ---- classification, lane = triangle (every wave for itself)
-        TriPlanes c;
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(triRec[lane]);
-            const float4 pa = src[0], pb = src[1], pc = src[2], bb = src[3];
-            c.A0 = pa.x; c.A1 = pa.y; c.A2 = pa.z; c.Dx = pa.w;
-            c.B0 = pb.x; c.B1 = pb.y; c.B2 = pb.z; c.Dy = pb.w;
-            c.C0 = pc.x; c.C1 = pc.y; c.C2 = pc.z; c.Dc = pc.w;
-            c.bbX0 = bb.x; c.bbX1 = bb.y; c.bbY0 = bb.z; c.bbY1 = bb.w;
-        }
+    // ---- the lane's triangle: its planes and box stay in registers for the whole view ...
+    TriPlanes c;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(triRec[lane]);
+        const float4 pa = src[0], pb = src[1], pc = src[2], bb = src[3];
+        c.A0 = pa.x; c.A1 = pa.y; c.A2 = pa.z; c.Dx = pa.w;
+        c.B0 = pb.x; c.B1 = pb.y; c.B2 = pb.z; c.Dy = pb.w;
+        c.C0 = pc.x; c.C1 = pc.y; c.C2 = pc.z; c.Dc = pc.w;
+        c.bbX0 = bb.x; c.bbX1 = bb.y; c.bbY0 = bb.z; c.bbY1 = bb.w;
+    }
+    // ---- ... and its classification against every tile of the group is worked out ONCE, wave w for tiles w, w + 8
+    //      (lane = triangle: box, then the planes at the tile's corner pixels, exact by monotonicity): a dword per
+    //      (tile, triangle) in the LDS the TLAS records occupied -- box origin and size inside the tile, small / live --
+    //      instead of every wave repeating ~70 dependent vector instructions at the head of every tile
+    //      (a group of ONE tile classifies in place: the table and its barrier cost one-tile views 2 %)
+    uint32_t *clsTab = reinterpret_cast<uint32_t *>(instRec);                  // [16][64]
+    auto classify = [&](uint32_t tg) -> uint32_t {
+        const uint32_t gx0 = (tg % tilesFast) * TW, gy0 = (tg / tilesFast) * TH;
+        const float TX0 = (float)gx0, TX1 = (float)(gx0 + TW - 1);
+        const float TY0 = (float)gy0, TY1 = (float)(gy0 + TH - 1);
         bool live = c.bbX1 >= TX0 && c.bbX0 <= TX1 && c.bbY1 >= TY0 && c.bbY0 <= TY1;
         {
             const float eMax0 = __builtin_fmaf(c.A0, c.A0 >= 0.0f ? TX1 : TX0, __builtin_fmaf(c.B0, c.B0 >= 0.0f ? TY1 : TY0, c.C0));
@@ -1475,9 +1483,29 @@ void bvhFlatKernel(const RasterParams p)
         const float fx0 = ceilf(fmaxf(c.bbX0 + kTrim, TX0)), fx1 = floorf(fminf(c.bbX1 - kTrim, TX1));
         const float fy0 = ceilf(fmaxf(c.bbY0 + kTrim, TY0)), fy1 = floorf(fminf(c.bbY1 - kTrim, TY1));
         live = live && fx0 <= fx1 && fy0 <= fy1;
-        const int ix0 = live ? (int)fx0 : 0, iy0 = live ? (int)fy0 : 0;
-        const int bw = live ? (int)fx1 - ix0 + 1 : 0, bh = live ? (int)fy1 - iy0 + 1 : 0;
-        const bool small = live && bw * bh <= smallArea;
+        const int jx0 = live ? (int)fx0 - (int)gx0 : 0, jy0 = live ? (int)fy0 - (int)gy0 : 0;
+        const int jw = live ? (int)fx1 - (int)fx0 : 0, jh = live ? (int)fy1 - (int)fy0 : 0;       // size - 1
+        const bool sm = (jw + 1) * (jh + 1) <= smallArea;
+        return live ? ((uint32_t)jx0 | ((uint32_t)jw << 6) | ((uint32_t)jy0 << 12) | ((uint32_t)jh << 18) |
+                       (sm ? 1u << 24 : 0u) | (1u << 25)) : 0u;
+    };
+    const bool table = left > 1u;
+    if (table) {
+        for (uint32_t g = (uint32_t)wave; g < left; g += kWaves)
+            clsTab[g * kWave + (uint32_t)lane] = classify(tile + g);
+        __syncthreads();
+    }
+    uint32_t buf = 0, g = 0;
+    for (;;) {
+        const uint32_t tileX0 = (tile % tilesFast) * TW, tileY0 = (tile / tilesFast) * TH;
+        const float TX0 = (float)tileX0;
+        const float TY0 = (float)tileY0;
+        unsigned long long *zb = zbuf + (size_t)buf * (kFlatZS * TH);
+        const uint32_t cls = table ? clsTab[g * kWave + (uint32_t)lane] : classify(tile);
+        const bool live = (cls >> 25) != 0u;
+        const int ix0 = (int)tileX0 + (int)(cls & 63u), iy0 = (int)tileY0 + (int)((cls >> 12) & 63u);
+        const int bw = live ? (int)((cls >> 6) & 63u) + 1 : 0, bh = live ? (int)((cls >> 18) & 63u) + 1 : 0;
+        const bool small = live && ((cls >> 24) & 1u) != 0u;
         const bool big = live && !small;
         // ---- small triangles by (triangle, row of its box), the items dealt over waves and lanes
         {
@@ -1592,6 +1620,7 @@ void bvhFlatKernel(const RasterParams p)
             zb[8 * wave * kFlatZS + i] = packHit(invFar, 0u);
         buf ^= 1u;
         ++tile;
+        ++g;
     }
     MRX_STAMP(6);
 #undef MRX_STAMP
