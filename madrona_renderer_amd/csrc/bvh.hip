@@ -1610,7 +1610,13 @@ void bvhFlatKernel(const RasterParams p)
             KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pk));
             const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
+#ifdef MRX_FLAT_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             resolveStrip<IDS, TEX, TW, TH, true, kFlatZS>(ra, zb, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
+#ifdef MRX_FLAT_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         MRX_STAMP(5);
         if (--left == 0)
