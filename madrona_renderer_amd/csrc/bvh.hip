@@ -1292,7 +1292,7 @@ void bvhTileKernel(const RasterParams p)
 // (Measured and not kept, profiles/r04_flat_whole_ab.txt: large triangles that cover a 32x8 half entirely --
 // all three edge planes >= 0 at the least favourable corner, the ground quad on most tiles -- walked with the
 // 1/depth plane alone: configs[4] 519.4 -> 516.2 us, one-tile views 1.3 % slower.  The vector instructions of
-// the large pass are not what a tile waits for.)
+// the large pass are not what a tile waits for.  Wave priority 1 for the resolve + stores of a strip: within noise.)
 // ---------------------------------------------------------------------------
 constexpr int kFlatTris = 64;                      // triangles and instance rows per world, at most
 // Row stride of the flat kernel's depth buffers, in pixels: 64 + 1.  A lane of a strip pass owns pixels
@@ -1610,13 +1610,7 @@ void bvhFlatKernel(const RasterParams p)
             KernargParams pk = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pk));
             const ResolveArgs ra = { pk->rgb, pk->depth, pk->ids, pk->texels, pk->nfast, pk->nslow, pk->writeThrough };
-#ifdef MRX_FLAT_PRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
             resolveStrip<IDS, TEX, TW, TH, true, kFlatZS>(ra, zb, shadeTab, coldTab, view, tileX0, tileY0, wave, lane);
-#ifdef MRX_FLAT_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         MRX_STAMP(5);
         if (--left == 0)
