@@ -370,3 +370,23 @@ def test_dispatch_constants_follow_the_cu_count(native):
         assert f(40, 8, 0, 64, 64, cus) == 40 and f(200, small, 0, 64, 64, cus) == 65
     # the MI355X values the measurements were taken at (profiles/r03_bvh_threshold.txt)
     assert f(0, 640, 1, 64, 64, 256) == 65 and f(0, 641, 0, 64, 64, 256) == 91 and f(0, 1025, 0, 64, 64, 256) == 129
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_device(native):
+    # ABI 4 additions: argument checks come before anything touches HIP
+    lib = native.load_capi()
+    lib.mrx_last_error.restype = ctypes.c_char_p
+    buf = (ctypes.c_uint8 * 96)()
+    lib.mrx_info_sized.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    assert lib.mrx_info_sized(None, ctypes.byref(buf), 80) == -1 and b"null" in lib.mrx_last_error()
+    assert lib.mrx_info(None, ctypes.byref(buf)) == -1
+    us = ctypes.c_double()
+    lib.mrx_time_steps_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    assert lib.mrx_time_steps_host(None, 10, ctypes.byref(us)) == -1
+    lib.mrx_shard_split.restype = ctypes.c_int64
+    lib.mrx_shard_split.argtypes = [ctypes.c_uint32] * 3
+    # the split every form of sharding uses (scenes.shard_range): contiguous, sizes differ by at most one
+    for worlds, n in ((16384, 8), (1003, 8), (7, 3), (5, 5)):
+        cuts = [lib.mrx_shard_split(worlds, i, n) for i in range(n + 1)]
+        assert cuts[0] == 0 and cuts[-1] == worlds
+        assert [(cuts[i], cuts[i + 1]) for i in range(n)] == [scenes.shard_range(worlds, i, n) for i in range(n)]
