@@ -1284,9 +1284,10 @@ void bvhTileKernel(const RasterParams p)
 //                   up); large triangles are rasterised by every wave over its own strip straight
 //                   from triRec (after the exact per-strip test of the CLS instantiations).  One
 //                   barrier -- walks done -- then resolve + output per strip as above.
-//   two depth buffers   tile i merges into buffer i & 1; a wave clears its strip of it after its
-//                   resolve, and the next use of that buffer lies behind the barrier of tile
-//                   i + 1: one barrier per tile instead of two.
+//   depth buffer    one (46 KB of LDS in all: three workgroups per CU): a wave clears its strip after its
+//                   resolve and a second barrier closes the tile.  The first form had two buffers -- tile i
+//                   merged into buffer i & 1, whose next use lay behind the barrier of tile i + 1: one barrier
+//                   per tile, 80 KB, two workgroups per CU -- and lost to this one (MRX_FLAT_ZBUFS above).
 // The pixel test, the (1/depth, lower index) order and the records are those of the general
 // kernel, so the output is the same bit for bit.  MRX_BVH_FLAT=0 keeps such worlds on it.
 // (Measured and not kept, profiles/r04_flat_whole_ab.txt: large triangles that cover a 32x8 half entirely --
@@ -1307,7 +1308,15 @@ constexpr int kFlatTris = 64;                      // triangles and instance row
 #define MRX_FLAT_ZS 64
 #endif
 constexpr int kFlatZS = MRX_FLAT_ZS;
-constexpr size_t kFlatZBytes = 2u * 64u * kFlatZS * 8u;
+// One depth buffer and two barriers per tile (46 KB of LDS: THREE workgroups per CU), or two buffers and one barrier
+// (80 KB: two per CU -- the first form of this kernel).  Occupancy is worth more than the barrier
+// (profiles/r04_flat_zbufs_ab.txt): 4096 x 128^2 + wall 145 -> 115 us, one-tile views 14.7 -> 13.9, configs[4] level in
+// either placement mode (495 / 498 us in the fast one).
+#ifndef MRX_FLAT_ZBUFS
+#define MRX_FLAT_ZBUFS 1
+#endif
+constexpr uint32_t kFlatZBufs = MRX_FLAT_ZBUFS;
+constexpr size_t kFlatZBytes = (size_t)kFlatZBufs * 64u * kFlatZS * 8u;
 constexpr size_t flatLdsBytes(bool tex)
 {
     return kFlatZBytes + kFlatTris * 64u + tabBytes(tex, kFlatTris + 2) + 16u +
@@ -1315,7 +1324,7 @@ constexpr size_t flatLdsBytes(bool tex)
 }
 
 template <int IDS, bool TEX>
-__global__ __launch_bounds__(kWave * 8, 4)
+__global__ __launch_bounds__(kWave * 8, MRX_FLAT_ZBUFS == 2 ? 4 : 6)
 void bvhFlatKernel(const RasterParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1352,7 +1361,7 @@ void bvhFlatKernel(const RasterParams p)
     const float invNear = p.invNear, invFar = p.invFar;
     if (wave != 0) {
         // both depth buffers, by the seven waves that have nothing to load
-        for (uint32_t i = (uint32_t)(wave - 1) * kWave + (uint32_t)lane; i < 2u * kFlatZS * TH; i += (kWaves - 1) * kWave)
+        for (uint32_t i = (uint32_t)(wave - 1) * kWave + (uint32_t)lane; i < kFlatZBufs * kFlatZS * TH; i += (kWaves - 1) * kWave)
             zbuf[i] = packHit(invFar, 0u);
     } else {
         // ---- phase I, lane = instance row of the view's world
@@ -1618,7 +1627,10 @@ void bvhFlatKernel(const RasterParams p)
         // this wave's strip of the buffer, for the tile after the next (behind the next tile's barrier)
         for (int i = lane; i < kFlatZS * 8; i += kWave)
             zb[8 * wave * kFlatZS + i] = packHit(invFar, 0u);
-        buf ^= 1u;
+        if (kFlatZBufs == 2)
+            buf ^= 1u;
+        else
+            __syncthreads();                          // (one buffer: every strip clear before anyone merges into it)
         ++tile;
         ++g;
     }

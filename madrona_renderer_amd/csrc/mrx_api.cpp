@@ -275,6 +275,7 @@ struct mrx_renderer {
     std::vector<mrx::TriMat> triMatsHost;
     mrx::BlasSet blas;
     uint32_t bvhMinTris = mrx::kBvhMinTris;
+    uint32_t bvhGroupTilesGeneral = 1;          // tiles of a view per workgroup as bvhTileKernel wants them (buildScene)
     // single-process multi-device (mrx_config.device_ids): a renderer that only fans out to
     // one sub-renderer per device, each owning a contiguous range of the worlds
     std::vector<mrx_renderer *> shards;
@@ -712,8 +713,33 @@ int chooseBvhGroups(mrx_renderer &r)
     p.bvhFlat = (p.bvhTile == 0 && r.info.max_world_triangles <= 64u && maxWorldInst <= 64u) ? 1u : 0u;
     if (const char *dbg = std::getenv("MRX_BVH_FLAT"))
         p.bvhFlat = p.bvhFlat && std::atoi(dbg) != 0;
-    if (p.bvhFlat)
+    p.bvhGroupTiles = r.bvhGroupTilesGeneral;
+    if (p.bvhFlat) {
+        // Tiles of a view per workgroup for the flat kernel (three workgroups per CU: 46 KB of LDS each).  A group pays
+        // one set-up of the view (S) and then a tile time (T) per tile, and the launch runs in ceil(groups / resident)
+        // generations: the run length -- the view's tiles divided by a power of two, at most 16 -- that minimises
+        // generations x (S + tiles x T).  S / T = 2.5 / 3.0 from the stamps (profiles/r04_flat_stamps.txt); measured
+        // (profiles/r04_flat_zbufs_ab.txt): 1024 x 128^2 picks 2 (39.0 us against 41.4 at 4 and 48.3 at 1), 4096 x 128^2
+        // picks 4 (115 against 137 / 166), 256^2 views pick 16.
+        const uint32_t tpvF = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
+        const uint32_t residentF = 3u * std::max(p.numCUs, 1u);
+        uint32_t best = 1;
+        double bestCost = 1e300;
+        for (uint32_t g = std::min(tpvF, 16u); g >= 1u; g = (g + 1u) / 2u) {
+            const uint64_t groups = (uint64_t)nviews * ((tpvF + g - 1) / g);
+            const double cost = (double)((groups + residentF - 1) / residentF) * (2.5 + 3.0 * (double)g);
+            if (cost < bestCost) {
+                bestCost = cost;
+                best = g;
+            }
+            if (g == 1u)
+                break;
+        }
+        p.bvhGroupTiles = best;
+        if (const char *dbg = std::getenv("MRX_BVH_GROUP_TILES"))
+            p.bvhGroupTiles = (uint32_t)std::max(1, std::min((int)tpvF, std::atoi(dbg)));
         return MRX_OK;
+    }
     const uint32_t resident = 2u * std::max(p.numCUs, 1u);
     const uint32_t tpv = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
     if (tpv == 1 && p.bvhTile == 0 && maxWorldInst <= p.bvhPassInst) {
@@ -1366,6 +1392,7 @@ int buildScene(const mrx_config &cfg, mrx_renderer &r)
         if (const char *dbg = std::getenv("MRX_BVH_GROUP_TILES"))
             p.bvhGroupTiles = (uint32_t)std::max(1, std::min((int)tpv, std::atoi(dbg)));
     }
+    r.bvhGroupTilesGeneral = p.bvhGroupTiles;         // (the flat kernel chooses its own: chooseBvhGroups)
     mrx_info_t &inf = r.info;
     inf.num_worlds = cfg.num_worlds;
     inf.num_views = nviews;
