@@ -720,7 +720,7 @@ int chooseBvhGroups(mrx_renderer &r)
         // generations: the run length -- the view's tiles divided by a power of two, at most 16 -- that minimises
         // generations x (S + tiles x T).  S / T = 2.5 / 3.0 from the stamps (profiles/r04_flat_stamps.txt); measured
         // (profiles/r04_flat_zbufs_ab.txt): 1024 x 128^2 picks 2 (39.0 us against 41.4 at 4 and 48.3 at 1), 4096 x 128^2
-        // picks 4 (115 against 137 / 166), 256^2 views pick 16.
+        // picks 4 (115 against 137 / 166), configs[4] (4096 views of 16 tiles) picks 8.
         const uint32_t tpvF = ((p.nfast + 63u) / 64u) * ((p.nslow + 63u) / 64u);
         const uint32_t residentF = 3u * std::max(p.numCUs, 1u);
         uint32_t best = 1;
