@@ -224,6 +224,10 @@ int mrx_refresh_objects(mrx_renderer *r);
  *    mrx_buffer(mrx_shard(r, i), ...).  On a renderer of several shards mrx_step / mrx_render /
  *    mrx_sync / mrx_refresh_objects / mrx_time_renders act on all of them, mrx_info adds up,
  *    and mrx_buffer / mrx_copy_to_host / mrx_set_stream want a shard (MRX_E_UNSUPPORTED). */
+/*    Host side: mrx_step has the launches enqueued by one thread per device and returns when all are queued
+ *    (MRX_SHARD_THREADS=0: by the calling thread, one after the other).  MRX_SHARD_ASYNC=1 in the environment of
+ *    mrx_create: mrx_step only posts the render to those threads and returns; every other entry point here, called
+ *    on the renderer or on one of its shards, waits for them to have enqueued everything posted. */
 int mrx_num_shards(mrx_renderer *r);
 mrx_renderer *mrx_shard(mrx_renderer *r, int shard);
 void *mrx_buffer_shard(mrx_renderer *r, int shard, int which, int64_t dims[4], int *ndim,

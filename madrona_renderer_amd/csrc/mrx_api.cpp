@@ -286,6 +286,9 @@ struct mrx_renderer {
     std::vector<ShardWorker *> workers;
     std::vector<mrx_renderer *> ownShards;      // (with workers) the shards the calling thread launches
     uint32_t workerSeq = 0;
+    bool shardAsync = false;                    // MRX_SHARD_ASYNC=1 (startShardWorkers)
+    uint32_t rendersPosted = 0;
+    mrx_renderer *parent = nullptr;             // of a shard: the renderer it belongs to
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // what choosePlacement measured (mrx_placement): us per render of every candidate
     // output allocation it timed, in order, and of the one it kept
@@ -361,6 +364,11 @@ struct ShardWorker {
     std::string err;
     int64_t tSeen = 0, tDone = 0;               // MRX_SHARD_TRACE: when the command was seen / finished
     alignas(64) std::atomic<uint32_t> masterSleeping { 0 };
+    // MRX_SHARD_ASYNC=1: renders are counted, not acknowledged one by one -- the caller posts (renderPosted)
+    // and goes on, the worker launches until it has caught up (renderDone); every other command joins first
+    bool async = false;
+    alignas(64) std::atomic<uint32_t> renderPosted { 0 };
+    alignas(64) std::atomic<uint32_t> renderDone { 0 };
 };
 
 namespace {
@@ -461,6 +469,23 @@ void shardWorkerMain(ShardWorker *w)
         const int cmd = w->cmd;
         if (shardTrace())
             w->tSeen = nowNs();
+        if (w->async) {
+            // counted renders: launch until caught up (a failure is kept for the next join and the
+            // count still advances, so that nobody waits for a launch that will not come)
+            uint32_t doneR = w->renderDone.load(std::memory_order_relaxed);
+            while (doneR != w->renderPosted.load(std::memory_order_acquire)) {
+                int rc = bound == hipSuccess ? groupRun(w->shards, kCmdRender, 0, false)
+                                             : fail(MRX_E_HIP, std::string("hipSetDevice (shard worker): ") + hipGetErrorString(bound));
+                if (rc != MRX_OK && w->rc == MRX_OK) {
+                    w->err = g_err;
+                    w->rc = rc;
+                }
+                w->renderDone.store(++doneR, std::memory_order_release);
+            }
+            lastWork = nowNs();
+            if (cmd == kCmdRender)
+                continue;                             // (nothing to acknowledge: the count is the acknowledgement)
+        }
         if (cmd == kCmdExit) {
             w->done.store(seq, std::memory_order_release);
             return;
@@ -470,9 +495,11 @@ void shardWorkerMain(ShardWorker *w)
             rc = fail(MRX_E_HIP, std::string("hipSetDevice (shard worker): ") + hipGetErrorString(bound));
         if (rc == MRX_OK)
             rc = groupRun(w->shards, cmd, w->steps, false);
-        w->rc = rc;
-        if (rc != MRX_OK)
-            w->err = g_err;
+        if (!(w->async && w->rc != MRX_OK)) {         // (an error of a counted render waits for its join)
+            w->rc = rc;
+            if (rc != MRX_OK)
+                w->err = g_err;
+        }
         if (shardTrace())
             w->tDone = nowNs();
         w->done.store(seq, std::memory_order_seq_cst);
@@ -480,6 +507,42 @@ void shardWorkerMain(ShardWorker *w)
             futexWake(&w->done);
         lastWork = nowNs();
     }
+}
+
+// MRX_SHARD_ASYNC: wait until every device thread has enqueued every render posted so far; the
+// first failure among them is reported here (and cleared)
+int joinRenders(mrx_renderer *r)
+{
+    if (!r->shardAsync)
+        return MRX_OK;
+    int rc = MRX_OK;
+    std::string err;
+    for (ShardWorker *w : r->workers) {
+        for (uint32_t it = 0; w->renderDone.load(std::memory_order_acquire) != r->rendersPosted; ++it) {
+            if ((it & 1023u) == 1023u)
+                std::this_thread::yield();
+            else
+                cpuRelax();
+        }
+        if (w->rc != MRX_OK) {
+            if (rc == MRX_OK) {
+                rc = w->rc;
+                err = w->err;
+            }
+            w->rc = MRX_OK;
+        }
+    }
+    return rc == MRX_OK ? MRX_OK : fail(rc, err);
+}
+
+// a renderer, or the renderer a shard handle belongs to: device threads caught up (MRX_SHARD_ASYNC)
+int settle(mrx_renderer *r)
+{
+    if (r && r->parent)
+        r = r->parent;
+    if (!r || !r->shardAsync)
+        return MRX_OK;
+    return joinRenders(r);
 }
 
 // run `cmd` on every shard of a multi-device renderer: workers in parallel, shard 0 (and any
@@ -499,6 +562,26 @@ int shardsRun(mrx_renderer *r, int cmd, int steps = 0)
             }
         }
         return MRX_OK;
+    }
+    if (r->shardAsync) {
+        if (cmd == kCmdRender) {
+            // post and go on; at most 256 renders ahead of the slowest device thread
+            const uint32_t n = ++r->rendersPosted;
+            const uint32_t seq = ++r->workerSeq;
+            for (ShardWorker *w : r->workers) {
+                while (n - w->renderDone.load(std::memory_order_acquire) > 256u)
+                    cpuRelax();
+                w->cmd = kCmdRender;
+                w->renderPosted.store(n, std::memory_order_release);
+                w->posted.store(seq, std::memory_order_seq_cst);
+                if (w->sleeping.load(std::memory_order_seq_cst))
+                    futexWake(&w->posted);
+            }
+            return MRX_OK;
+        }
+        const int jrc = joinRenders(r);
+        if (jrc != MRX_OK)
+            return jrc;
     }
     const uint32_t seq = ++r->workerSeq;
     const bool trace = shardTrace() && cmd == kCmdRender;
@@ -578,10 +661,21 @@ void startShardWorkers(mrx_renderer *r)
     }
     if (groups.size() <= 1)
         return;
-    r->ownShards = groups[0];
-    for (size_t g = 1; g < groups.size(); ++g) {
+    // MRX_SHARD_ASYNC=1 (opt-in): mrx_step only POSTS the render -- every device, the first included, has a
+    // thread -- and returns; the threads enqueue behind its back, and every other mrx_* call on the renderer or
+    // on one of its shards joins them first (mrx_sync, mrx_buffer ..., the next non-render command).  The host
+    // pays a cache line per device for a step, not a launch.  What the caller gives up: an operation it enqueues
+    // ITSELF on a shard's stream right after mrx_step (a torch kernel on tensors fetched earlier) is no longer
+    // ordered behind the render unless an mrx_* call came in between.
+    if (const char *e = std::getenv("MRX_SHARD_ASYNC"))
+        r->shardAsync = std::atoi(e) != 0;
+    const size_t firstWorker = r->shardAsync ? 0 : 1;
+    if (!r->shardAsync)
+        r->ownShards = groups[0];
+    for (size_t g = firstWorker; g < groups.size(); ++g) {
         ShardWorker *w = new ShardWorker();
         w->shards = groups[g];
+        w->async = r->shardAsync;
         w->th = std::thread(shardWorkerMain, w);
         r->workers.push_back(w);
     }
@@ -1677,6 +1771,7 @@ int mrx_create(const mrx_config *cfgIn, mrx_renderer **out)
             delete top;                               // (destroys the shards made so far)
             return fail(rc, "shard " + std::to_string(i) + " (device " + std::to_string(sub.gpu_id) + "): " + why);
         }
+        sh->parent = top;
         top->shards.push_back(sh);
         top->shardFirstWorld.push_back(lo);
     }
@@ -1704,6 +1799,11 @@ void mrx_destroy(mrx_renderer *r)
 
 int mrx_render(mrx_renderer *r)
 {
+    if (r && r->parent) {                             // (a shard stepped on its own: behind what its renderer posted)
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
     // several devices: one launch each, enqueued concurrently by the shards' host threads
@@ -1728,6 +1828,11 @@ int mrx_step(mrx_renderer *r)
 
 int mrx_sync(mrx_renderer *r)
 {
+    if (r && r->parent) {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
     if (!r->shards.empty())
@@ -1781,6 +1886,11 @@ int64_t mrx_shard_first_world(mrx_renderer *r, int shard)
 
 int mrx_refresh_objects(mrx_renderer *r)
 {
+    {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
     for (mrx_renderer *sh : r->shards) {
@@ -1815,6 +1925,11 @@ int mrx_refresh_objects(mrx_renderer *r)
 
 int mrx_set_stream(mrx_renderer *r, void *stream)
 {
+    {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r)
         return fail(MRX_E_INVALID, "null renderer");
     if (!r->shards.empty())
@@ -1832,6 +1947,8 @@ int mrx_set_stream(mrx_renderer *r, void *stream)
 void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dtype,
                  int *device)
 {
+    if (settle(r) != MRX_OK)
+        return nullptr;
     if (!r || !dims || !ndim || !dtype) {
         fail(MRX_E_INVALID, "null argument");
         return nullptr;
@@ -1904,6 +2021,11 @@ void *mrx_buffer(mrx_renderer *r, int which, int64_t dims[4], int *ndim, int *dt
 
 int mrx_copy_to_host(mrx_renderer *r, int which, void *dst, uint64_t bytes)
 {
+    {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r || !dst)
         return fail(MRX_E_INVALID, "null argument");
     if (!r->shards.empty())
@@ -1993,6 +2115,11 @@ int mrx_time_steps_host(mrx_renderer *r, int steps, double *us_per_step)
 
 int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
 {
+    if (r && r->parent) {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r || !ms_total || steps < 0)
         return fail(MRX_E_INVALID, "bad argument");
     if (!r->shards.empty()) {
@@ -2025,6 +2152,8 @@ int mrx_time_renders(mrx_renderer *r, int steps, float *ms_total)
 
 int64_t mrx_debug_stamps(mrx_renderer *r, uint64_t *dst, int64_t capacity)
 {
+    if (settle(r) != MRX_OK)
+        return 0;
     if (r && !r->shards.empty())
         r = r->shards[0];
     if (!r || !dst || !r->stamps.ptr)
@@ -2038,6 +2167,11 @@ int64_t mrx_debug_stamps(mrx_renderer *r, uint64_t *dst, int64_t capacity)
 
 int mrx_mark(mrx_renderer *r, int which)
 {
+    {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r || (which != 0 && which != 1))
         return fail(MRX_E_INVALID, "bad argument");
     for (mrx_renderer *sh : r->shards) {
@@ -2054,6 +2188,11 @@ int mrx_mark(mrx_renderer *r, int which)
 
 int mrx_elapsed_ms(mrx_renderer *r, float *ms)
 {
+    {
+        const int src = settle(r);
+        if (src != MRX_OK)
+            return src;
+    }
     if (!r || !ms)
         return fail(MRX_E_INVALID, "null argument");
     if (!r->shards.empty()) {                     // the slowest device

@@ -27,8 +27,9 @@ BURST = 40
 REPS = 25
 
 
-def measure(shards, threads, own_streams):
+def measure(shards, threads, own_streams, async_steps=False):
     os.environ["MRX_SHARD_THREADS"] = "2" if threads else "0"
+    os.environ["MRX_SHARD_ASYNC"] = "1" if async_steps else "0"
     desc = scenes.synthetic_scene(WORLDS)
     r = scenes.make_renderer(desc, device_ids=[0] * shards if shards > 1 else None)
     streams = []
@@ -67,6 +68,12 @@ def main():
                       (n, "threads" if threads and n > 1 else "calling thread",
                        "per shard" if own else "null", med, lo, dev, med / base[own]))
                 sys.stdout.flush()
+    # opt-in MRX_SHARD_ASYNC=1: step() posts the render to the device threads and returns
+    for n in (2, 4, 8):
+        med, lo, dev = measure(n, True, True, async_steps=True)
+        print("%-7d %-22s %-14s %9.2f (%6.2f) %14.2f   x%.2f of 1 shard" %
+              (n, "threads, posted (async)", "per shard", med, lo, dev, med / base[True]))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

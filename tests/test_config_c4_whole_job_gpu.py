@@ -79,9 +79,15 @@ def test_serial_and_threaded_multi_device_steps_agree(native, monkeypatch):
     import torch
     desc = scenes.synthetic_scene(1003)          # ragged: 1003 = 8 * 125 + 3
     rs = []
-    for threads in ("0", "2", None):
+    for threads in ("0", "2", None, "async"):
+        monkeypatch.delenv("MRX_SHARD_ASYNC", raising=False)
         if threads is None:
             monkeypatch.delenv("MRX_SHARD_THREADS")
+        elif threads == "async":
+            # opt-in: step() only posts the render to the device threads; every other call joins them first
+            # (here: the tensor getters ahead of the next pose write, sync() at the end)
+            monkeypatch.setenv("MRX_SHARD_THREADS", "2")
+            monkeypatch.setenv("MRX_SHARD_ASYNC", "1")
         else:
             monkeypatch.setenv("MRX_SHARD_THREADS", threads)
         rs.append(scenes.make_renderer(desc, device_ids=[0] * SHARDS))
@@ -90,10 +96,10 @@ def test_serial_and_threaded_multi_device_steps_agree(native, monkeypatch):
             for i in range(SHARDS):
                 r.instance_position_tensor(shard=i).to_torch()[1::2, 2] += 0.25
             r.step()
-    a, b, c = (_slabs(r, SHARDS, False) for r in rs)
+    a, b, c, e = (_slabs(r, SHARDS, False) for r in rs)
     for k in a:
-        for x, y, z in zip(a[k], b[k], c[k]):
-            assert torch.equal(x, y) and torch.equal(x, z), k
+        for x, y, z, u in zip(a[k], b[k], c[k], e[k]):
+            assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(x, u), k
     moved = scenes.synthetic_scene(1003)
     inst = list(moved.instances)
     for row in range(1, len(inst), 2):
@@ -106,7 +112,12 @@ def test_serial_and_threaded_multi_device_steps_agree(native, monkeypatch):
     rgb = torch.cat(a["rgb"]).cpu().numpy()
     depth = torch.cat(a["depth"]).cpu().numpy().reshape(1003, 64, 64)
     assert_parity({"rgb": rgb, "depth": depth}, ref)
-    assert rs[1].time_steps_host(20) > 0 and rs[0].time_steps_host(20) > 0
+    assert rs[1].time_steps_host(20) > 0 and rs[0].time_steps_host(20) > 0 and rs[3].time_steps_host(300) > 0
+    # (300 posted steps in a row: more than the device threads enqueue in the meantime -- the count catches up at the join)
+    after = _slabs(rs[3], SHARDS, False)
+    for k in a:
+        for x, u in zip(a[k], after[k]):
+            assert torch.equal(x, u), k
 
 
 def test_mrx_info_keeps_the_abi2_size_and_the_sized_call_gives_the_rest(native):
@@ -141,15 +152,16 @@ def test_shard_threads_survive_bursts_idle_gaps_and_interleaved_calls(native, mo
     import time
     import torch
     desc = scenes.synthetic_scene(257)
-    for spin in ("50", "0"):
+    for spin, async_steps in (("50", "0"), ("0", "0"), ("50", "1")):
         monkeypatch.setenv("MRX_SHARD_THREADS", "2")
         monkeypatch.setenv("MRX_SHARD_SPIN_US", spin)
+        monkeypatch.setenv("MRX_SHARD_ASYNC", async_steps)
         many = scenes.make_renderer(desc, device_ids=[0] * 5)
         one = scenes.make_renderer(desc)
         streams = [torch.cuda.Stream() for _ in range(5)]
         for i, s in enumerate(streams):
             many.set_stream(s.cuda_stream, shard=i)
-        rng = np.random.default_rng(int(spin) + 1)
+        rng = np.random.default_rng(int(spin) + 1 + 7 * int(async_steps))
         pos1 = one.instance_position_tensor().to_torch()
         for burst in range(60):
             dz = float(np.float32(rng.uniform(-0.05, 0.05)))
