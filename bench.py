@@ -86,6 +86,8 @@ def parse(argv=None):
                     help="skip the secondary 1024-world measurement")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the BASELINE configs[2] / configs[4] entries (`also_configs`)")
+    ap.add_argument("--no-multidev", action="store_true",
+                    help="skip the one-Manager multi-shard host-cost entry (`also_multidev`)")
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the configs[3] strong-scaling measurement")
     ap.add_argument("--strong-worlds", type=int, default=STRONG_WORLDS,
@@ -573,6 +575,41 @@ def run_rank(a):
                             "placement": rc.placement()})
             del rc
         out["also_configs"] = entries
+
+    if n_gpus == 1 and not a.no_extra and not a.no_multidev and a.variant == 0 and not a.cubes:
+        # BASELINE configs[3] in the one-Manager form every reference caller uses (one constructor, one step():
+        # /root/reference/scripts/test.py:112-130): ONE renderer of eight shards -- all on this device, each on a stream
+        # of its own (a node has eight devices) -- and what one step() costs the HOST: every launch from the calling
+        # thread (the round-3 form), a host thread per shard (default on a node), and MRX_SHARD_ASYNC=1 (step() posts the
+        # render to the device threads; every other call joins them).  Median over bursts of 40 back-to-back steps.
+        import statistics
+        dmd = scenes.synthetic_scene(a.strong_worlds)
+        md = {"workload": "%d worlds x 64x64 cube+plane in ONE renderer of 8 shards on one device (rehearsal of a node)"
+                          % a.strong_worlds, "unit": "host us per step()"}
+        keep = {k: os.environ.get(k) for k in ("MRX_SHARD_THREADS", "MRX_SHARD_ASYNC")}
+        try:
+            for key, thr, asy, shards in (("one_shard", "0", "0", 1), ("eight_shards_calling_thread", "0", "0", 8),
+                                          ("eight_shards_threads", "2", "0", 8), ("eight_shards_threads_async", "2", "1", 8)):
+                os.environ["MRX_SHARD_THREADS"], os.environ["MRX_SHARD_ASYNC"] = thr, asy
+                rm = scenes.make_renderer(dmd, gpu_id=local, device_ids=[local] * shards if shards > 1 else None)
+                streams = [torch.cuda.Stream() for _ in range(shards)]
+                for i, st in enumerate(streams):
+                    if shards > 1:
+                        rm.set_stream(st.cuda_stream, shard=i)
+                    else:
+                        rm.set_stream(st.cuda_stream)
+                rm.time_steps_host(40)
+                md[key] = statistics.median(rm.time_steps_host(40) for _ in range(15))
+                if shards > 1 and thr == "2" and asy == "0":
+                    md["device_us_per_step"] = rm.time_renders(200) * 1000.0 / 200
+                del rm, streams
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        out["also_multidev"] = md
 
     if not a.no_strong:
         # BASELINE.json configs[3]: 16384 worlds x 64x64 cube+plane IN TOTAL, world-sharded:
