@@ -1364,12 +1364,32 @@ void bvhFlatKernel(const RasterParams p)
         for (uint32_t i = (uint32_t)(wave - 1) * kWave + (uint32_t)lane; i < kFlatZBufs * kFlatZS * TH; i += (kWaves - 1) * kWave)
             zbuf[i] = packHit(invFar, 0u);
     } else {
+        ViewConst vc;
+        loadViewConst(p, view, vc);
+        InstXform y;
+        int32_t objL = -1;
+        uint32_t myTri = 0;
+        bool hasT = false;
+        if (p.uniInstances != 0) {
+            // ---- uniform worlds (every world the same <= 4 objects in the same order: every BASELINE scene): which row
+            //      and which object triangle lane k sets up is arithmetic on kernel arguments (raster.hpp), so its
+            //      pose, camera and geometry loads are all requested at once -- one load level, no TLAS records in LDS
+            const uint32_t world = p.uniCamsPerWorld > 1u ? view / p.uniCamsPerWorld : view;
+            const uint32_t k = (uint32_t)lane;
+            uint32_t i = (k >= p.uniPrefix[1] ? 1u : 0u) + (k >= p.uniPrefix[2] ? 1u : 0u) + (k >= p.uniPrefix[3] ? 1u : 0u);
+            i = min(i, p.uniInstances - 1u);
+            hasT = k < p.uniPrefix[4];
+            const uint32_t pre = i == 0u ? 0u : i == 1u ? p.uniPrefix[1] : i == 2u ? p.uniPrefix[2] : p.uniPrefix[3];
+            const uint32_t ft = i == 0u ? p.uniFirstTri[0] : i == 1u ? p.uniFirstTri[1] : i == 2u ? p.uniFirstTri[2] : p.uniFirstTri[3];
+            myTri = hasT ? ft + (k - pre) : 0u;
+            const uint32_t row = world * p.uniInstances + i;
+            objL = p.instObj[row];
+            instanceTransform(p, vc, row, y);
+        } else {
         // ---- phase I, lane = instance row of the view's world
         uint32_t i0, i1;
         viewInstances(p, view, i0, i1);
         const uint32_t nI = min(i1 - i0, (uint32_t)kFlatTris);
-        ViewConst vc;
-        loadViewConst(p, view, vc);
         const bool hasI = (uint32_t)lane < nI;
         uint32_t kBase = 0, firstI = 0, numI = 0;
         if (nI != 0) {                                // (an empty world has no row to read)
@@ -1393,8 +1413,7 @@ void bvhFlatKernel(const RasterParams p)
         // ---- lane = world-local triangle k: the instance that draws it is the row whose
         //      [kBase, kBase + count) holds k (rows are in index order; a hidden or unbound row
         //      keeps its range and fails the validity test of the set-up)
-        uint32_t myInst = 0, myTri = 0;
-        bool hasT = false;
+        uint32_t myInst = 0;
         for (uint32_t j = 0; j < nI; ++j) {
             const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)kBase, (int)j);
             const uint32_t nt = (uint32_t)__builtin_amdgcn_readlane((int)numI, (int)j);
@@ -1405,20 +1424,22 @@ void bvhFlatKernel(const RasterParams p)
             hasT = hasT || in;
         }
         waveLdsSync();                                // the records written above are read below
-        TriPlanes c;
-        c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
-        c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
-        bool valid = false;
         if (hasT) {
             const float4 *rec = reinterpret_cast<const float4 *>(instRec + (size_t)myInst * kInstRecDw);
             const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
-            InstXform y;
             y.MV[0][0] = a0.x; y.MV[0][1] = a0.y; y.MV[0][2] = a0.z; y.MV[1][0] = a0.w;
             y.MV[1][1] = a1.x; y.MV[1][2] = a1.y; y.MV[2][0] = a1.z; y.MV[2][1] = a1.w;
             y.MV[2][2] = a2.x; y.tv[0] = a2.y; y.tv[1] = a2.z; y.tv[2] = a2.w;
             y.qo[0] = a3.x; y.qo[1] = a3.y; y.qo[2] = a3.z; y.det = a3.w;
             y.sc[0] = a4.x; y.sc[1] = a4.y; y.sc[2] = a4.z;
-            const int32_t objL = __float_as_int(a4.w);
+            objL = __float_as_int(a4.w);
+        }
+        }
+        TriPlanes c;
+        c.A0 = c.B0 = c.C0 = c.A1 = c.B1 = c.C1 = 0.0f;
+        c.A2 = c.B2 = c.C2 = c.Dx = c.Dy = c.Dc = 0.0f;
+        bool valid = false;
+        if (hasT) {
             float shade[4] = { 0.f, 0.f, 0.f, 0.f }, cold[kCold];
             valid = setupTriangleCore<false>(p, vc.lv, y, myTri, objL, (int32_t)lane, c, shade, cold);
             if (!TEX)
