@@ -88,7 +88,10 @@ typedef struct {
 enum {
     /* also write a per-pixel int32 visibility buffer (world-local triangle
      * index, -1 = background); parity tests use it for bit-exact checks */
-    MRX_FLAG_VISIBILITY_IDS = 1u << 0
+    MRX_FLAG_VISIBILITY_IDS = 1u << 0,
+    /* several devices (device_ids): mrx_step only posts the render to the per-device host threads and returns;
+     * every other entry point joins them first (the same as MRX_SHARD_ASYNC=1 in the environment) */
+    MRX_FLAG_SHARD_ASYNC = 1u << 1
 };
 
 /* Manager::Config + Config::RenderConfig, /root/reference/src/mgr.hpp:49-88.

@@ -667,6 +667,7 @@ void startShardWorkers(mrx_renderer *r)
     // pays a cache line per device for a step, not a launch.  What the caller gives up: an operation it enqueues
     // ITSELF on a shard's stream right after mrx_step (a torch kernel on tensors fetched earlier) is no longer
     // ordered behind the render unless an mrx_* call came in between.
+    r->shardAsync = (r->flags & MRX_FLAG_SHARD_ASYNC) != 0;
     if (const char *e = std::getenv("MRX_SHARD_ASYNC"))
         r->shardAsync = std::atoi(e) != 0;
     const size_t firstWorker = r->shardAsync ? 0 : 1;
