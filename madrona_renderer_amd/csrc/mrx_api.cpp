@@ -355,8 +355,8 @@ struct ShardWorker {
     std::thread th;
     // written by the master, read by the worker
     alignas(64) std::atomic<uint32_t> posted { 0 };
-    int cmd = kCmdNone;
-    int steps = 0;
+    std::atomic<int> cmd { kCmdNone };          // (ordered by `posted`; atomic because MRX_SHARD_ASYNC re-posts kCmdRender
+    std::atomic<int> steps { 0 };               //  while the worker may still be looking at the previous one)
     alignas(64) std::atomic<uint32_t> sleeping { 0 };
     // written by the worker, read by the master
     alignas(64) std::atomic<uint32_t> done { 0 };
@@ -466,7 +466,7 @@ void shardWorkerMain(ShardWorker *w)
             cpuRelax();
         }
         seen = seq;
-        const int cmd = w->cmd;
+        const int cmd = w->cmd.load(std::memory_order_relaxed);
         if (shardTrace())
             w->tSeen = nowNs();
         if (w->async) {
@@ -494,7 +494,7 @@ void shardWorkerMain(ShardWorker *w)
         if (bound != hipSuccess)
             rc = fail(MRX_E_HIP, std::string("hipSetDevice (shard worker): ") + hipGetErrorString(bound));
         if (rc == MRX_OK)
-            rc = groupRun(w->shards, cmd, w->steps, false);
+            rc = groupRun(w->shards, cmd, w->steps.load(std::memory_order_relaxed), false);
         if (!(w->async && w->rc != MRX_OK)) {         // (an error of a counted render waits for its join)
             w->rc = rc;
             if (rc != MRX_OK)
