@@ -47,6 +47,19 @@ def test_small_batches_and_the_bvh_path_are_not_grossly_slower(native, monkeypat
     assert bvh < 31.0, f"1024 worlds x 482 triangles: {bvh:.1f} us (round 3: 21.7, round 2: 27.0)"
 
 
+def test_the_bvh_path_on_the_configs4_shape_is_not_grossly_slower(native, monkeypatch, capsys):
+    # round 4: worlds of <= 64 triangles forced onto the BVH path take the flat kernel -- an eighth of
+    # BASELINE configs[4] (512 views x 256x256 Raytracer, textured cube + plane): 73 - 92 us by placement mode; the general
+    # kernel took 119 - 155 (profiles/r03_bvh_group_tiles.txt), and MRX_BVH_FLAT=0 still shows it
+    monkeypatch.setenv("MADRONA_MI355_KERNEL", "2")
+    d = scenes.synthetic_scene(512, width=256, height=256, textured=True, render_mode="Raytracer")
+    flat = _us(d, 100)
+    general = _us(d, 100, {"MRX_BVH_FLAT": "0"}, monkeypatch)
+    with capsys.disabled():
+        print(f"\n[perf] 512 x 256^2 RT textured through the BVH path: flat kernel {flat:.1f} us, general kernel {general:.1f} us")
+    assert flat < 125.0 and flat < general, f"flat kernel {flat:.1f} us, general kernel {general:.1f} us"
+
+
 def test_report_headline_time_in_this_process(native, monkeypatch, capsys):
     # diagnostic line for the log: the headline time with one try and with the search
     monkeypatch.setenv("MRX_PLACEMENT_TRIES", "1")
