@@ -507,7 +507,39 @@ def run_rank(a):
             pos.add_(delta)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        # ... and the same loop captured ONCE into a hipGraph and replayed (step() is one launch with nothing a capture
+        # rejects; tests/test_parity_gpu.py::test_step_can_be_captured...): what a launch-bound caller does
+        try:
+            side = torch.cuda.Stream()
+            r.set_stream(side.cuda_stream)
+            graph = torch.cuda.CUDAGraph()
+            per_graph = 20
+            with torch.cuda.stream(side):
+                r.step()
+                side.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(per_graph):
+                        pos.add_(delta)
+                        r.step()
+                for _ in range(5):
+                    graph.replay()
+                side.synchronize()
+                reps = max(1, k5 // per_graph)
+                tg0 = time.perf_counter()
+                for _ in range(reps):
+                    graph.replay()
+                side.synchronize()
+                tg1 = time.perf_counter()
+            graph_ms = (tg1 - tg0) * 1000.0 / (reps * per_graph)
+            del graph
+        except Exception as e:                       # (a capture the runtime refuses is reported, not fatal)
+            graph_ms = None
+            print("note: hipGraph capture of the loop failed: %r" % (e,), file=sys.stderr)
+        finally:
+            torch.cuda.synchronize()
+            r.set_stream(0)
         out["also_loop"] = {"workload": "the batch above, a pose update (torch add_ on the instance positions) ahead of every render",
+                            "ms_per_iteration_graph_replay": graph_ms,
                             "iterations": k5, "ms_per_iteration": (t1 - t0) * 1000.0 / k5,
                             "ms_update_alone": (t2 - t1) * 1000.0 / k5,
                             "ms_per_step_back_to_back": wall * 1000.0 / a.steps}

@@ -64,6 +64,8 @@ def test_bench_extras_configs1_and_the_bvh_path(native):
     assert abs(bv["roofline"]["peak"] - 1228.8) < 1e-6 and isinstance(bv["roofline"]["stale"], bool)
     lp = out["also_loop"]
     assert lp["ms_per_iteration"] > lp["ms_update_alone"] > 0 and lp["iterations"] == 100
+    # the same loop captured once into a hipGraph and replayed: never slower than launching it piece by piece
+    assert 0 < lp["ms_per_iteration_graph_replay"] <= lp["ms_per_iteration"] * 1.05
     # BASELINE configs[2] and configs[4] (default dispatch and the BVH path the config names) at full size
     cf = out["also_configs"]
     assert [c["render_path"] for c in cf] == ["raster", "raster", "bvh"]
