@@ -580,16 +580,16 @@ def run_rank(a):
     if n_gpus == 1 and not a.no_extra and not a.no_configs and a.variant == 0 and not a.cubes:
         # BASELINE.json configs[2] and configs[4] at their full size, so that the driver's own run carries them:
         # 4096 x 128x128 cube+plane+wall (tiled raster), 4096 x 256x256 Raytracer textured cube+plane through the
-        # default dispatch (tiled raster kernel) and through the BVH ray-trace path the config names (kernel_variant
-        # 2: bvhFlatKernel).  Outputs of 0.5 - 3 GiB: `placement` says which mode the allocation got.
+        # default dispatch (the BVH ray-trace path the config names: bvhFlatKernel) and through the
+        # tiled raster kernel (kernel_variant 3).  Outputs of 0.5 - 3 GiB: `placement` says which mode the allocation got.
         entries = []
         for label, kw, variant, k in (
                 ("configs[2]: 4096 worlds x 128x128 cube+plane+wall, tiled raster",
                  dict(width=128, height=128, with_wall=True), 0, 300),
-                ("configs[4]: 4096 worlds x 256x256 Raytracer, textured cube+plane, default dispatch (tiled raster kernel)",
-                 dict(width=256, height=256, textured=True, render_mode="Raytracer"), 0, 60),
-                ("configs[4] through the BVH ray-trace path (kernel_variant 2)",
-                 dict(width=256, height=256, textured=True, render_mode="Raytracer"), 2, 60)):
+                ("configs[4]: 4096 worlds x 256x256 Raytracer, textured cube+plane, default dispatch (the BVH ray-trace path: "
+                 "bvhFlatKernel)", dict(width=256, height=256, textured=True, render_mode="Raytracer"), 0, 60),
+                ("configs[4] through the tiled raster kernel (kernel_variant 3)",
+                 dict(width=256, height=256, textured=True, render_mode="Raytracer"), 3, 60)):
             if variant:
                 os.environ["MADRONA_MI355_KERNEL"] = str(variant)
             try:

@@ -122,7 +122,9 @@ typedef struct {
     uint32_t flags;             /* MRX_FLAG_* */
     int32_t kernel_variant;     /* 0 = default (raster kernels up to 128 triangles per
                                  * world, BVH path from 129 -- from 65 for batches of up to 640
-                                 * 64x64 views, from 91 for up to 1024 untextured ones);
+                                 * 64x64 views, from 91 for up to 1024 untextured ones; and for
+                                 * Raytracer-mode batches of many large views of small worlds:
+                                 * mrx_dispatch_flat);
                                  * 1 = brute-force cross-check;
                                  * 2 = BVH path always; 3 = raster kernels always */
     /* -- ABI 3 (a caller that sets struct_size = MRX_CONFIG_V2_SIZE passes none of these) --
@@ -327,6 +329,11 @@ void mrx_free(void *p);
 uint32_t mrx_dispatch_min_tris(uint32_t base, uint32_t num_views, int textured, uint32_t width, uint32_t height,
                                uint32_t num_cus);
 uint32_t mrx_group_fill(uint32_t num_cus);
+/*    ... and whether the default dispatch gives a Raytracer-mode batch of small worlds (<= 64 triangles in <= 64
+ *    rows) to the BVH path (its flat kernel) rather than to the raster kernels: views of >= 16 tiles, >= 192 tiles per
+ *    compute unit in the batch (BASELINE configs[4]); 1 / 0. */
+int mrx_dispatch_flat(int raytracer, uint32_t num_views, uint32_t width, uint32_t height, uint32_t max_world_triangles,
+                      uint32_t max_world_instances, uint32_t num_cus);
 
 int mrx_device_count(void);
 int mrx_abi_version(void);

@@ -946,7 +946,14 @@ int bindGeometry(mrx_renderer &r)
         if (!std::getenv("MRX_BVH_MIN_TRIS"))
             minTris = bvhDispatchMinTris(minTris, nviews, anyTex, r.params.nfast, r.params.nslow, r.params.numCUs);
     }
-    r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && maxWorldTris >= minTris);
+    // (Raytracer-mode batches of many large views of small worlds: the BVH path's flat kernel -- what BASELINE configs[4]
+    // names -- is ahead of the raster kernel there; raster.hpp bvhDispatchFlat.  MRX_BVH_FLAT=0 / MRX_BVH_MIN_TRIS: off)
+    bool rtFlat = bvhDispatchFlat(r.mode == MRX_MODE_RAYTRACER, (uint32_t)viewWorld.size(), r.params.nfast, r.params.nslow,
+                                  maxWorldTris, r.info.max_world_instances, r.params.numCUs) &&
+                  !std::getenv("MRX_BVH_MIN_TRIS") && r.params.bvhTile == 0;
+    if (const char *dbg = std::getenv("MRX_BVH_FLAT"))
+        rtFlat = rtFlat && std::atoi(dbg) != 0;
+    r.useBvh = r.variant == kVariantBvh || (r.variant == kVariantDefault && (maxWorldTris >= minTris || rtFlat));
     if (r.useBvh && maxWorldTris > kBvhMaxWorldTris)
         return fail(MRX_E_UNSUPPORTED, "more than 2M triangles in one world");
     // per-view draw lists with a fixed stride (one load level in the kernel);
@@ -2364,6 +2371,14 @@ uint32_t mrx_dispatch_min_tris(uint32_t base, uint32_t num_views, int textured, 
 }
 
 uint32_t mrx_group_fill(uint32_t num_cus) { return mrx::groupFill(num_cus); }
+
+int mrx_dispatch_flat(int raytracer, uint32_t num_views, uint32_t width, uint32_t height, uint32_t max_world_triangles,
+                      uint32_t max_world_instances, uint32_t num_cus)
+{
+    // (Raytracer storage is square: res = width)
+    return mrx::bvhDispatchFlat(raytracer != 0, num_views, width, raytracer ? width : height, max_world_triangles,
+                                max_world_instances, num_cus) ? 1 : 0;
+}
 
 int mrx_blas_check(const float *tri_pos, uint32_t num_tris, uint32_t *num_nodes, uint32_t *depth,
                    uint32_t *num_leaves)

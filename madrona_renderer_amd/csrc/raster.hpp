@@ -244,6 +244,21 @@ inline uint32_t bvhDispatchMinTris(uint32_t base, uint32_t numViews, bool anyTex
     return base;
 }
 
+// Raytracer-mode batches of small worlds that the default dispatch gives to the BVH path's flat kernel (bvh.hip,
+// bvhFlatKernel: worlds of <= 64 triangles in <= 64 rows) instead of the raster group kernel: views of at least 16
+// tiles, at least 192 tiles per compute unit in the batch -- BASELINE configs[4], 4096 views of 256x256 = 65536 tiles on 256
+// CUs, is the measured case (474 - 483 us against 488 - 494 on the same boxes, profiles/r04_c5_shape_by_views.txt,
+// r04_bench_k20_kernel_stats.csv); at 2048 views and fewer, and in Rasterizer mode (no segmask: two output tensors), the
+// raster kernel is ahead by 1 - 3 % and keeps the batch.
+inline bool bvhDispatchFlat(bool raytracer, uint32_t numViews, uint32_t nfast, uint32_t nslow, uint32_t maxWorldTris,
+                            uint32_t maxWorldInstances, uint32_t numCUs)
+{
+    const uint32_t cus = numCUs ? numCUs : 256u;
+    const uint64_t tpv = (uint64_t)((nfast + 63u) / 64u) * ((nslow + 63u) / 64u);
+    return raytracer && maxWorldTris >= 1u && maxWorldTris <= 64u && maxWorldInstances <= 64u && tpv >= 16u &&
+           (uint64_t)numViews * tpv >= 192ull * cus;
+}
+
 hipError_t launchRaster(const RasterParams &p, uint32_t maxWorldTris,
                         int32_t variant, hipStream_t stream);
 

@@ -22,6 +22,7 @@ CONFIGS = {   # name -> (pmc_latest key, bench args)
     "c3": ("4096x128x128+wall", "--worlds 4096 --width 128 --height 128 --wall"),
     "c5": ("4096x256x256+tex+rt", "--worlds 4096 --width 256 --height 256 --textured --mode Raytracer"),
     "c5bvh": ("4096x256x256+tex+rt+variant2", "--worlds 4096 --width 256 --height 256 --textured --mode Raytracer --variant 2"),
+    "c5raster": ("4096x256x256+tex+rt+variant3", "--worlds 4096 --width 256 --height 256 --textured --mode Raytracer --variant 3"),
     "bvh482": ("1024x64x64+cubes40", "--worlds 1024 --cubes 40"),
     "bvh1202": ("1024x64x64+cubes100", "--worlds 1024 --cubes 100"),
 }

@@ -20,5 +20,6 @@ run c4shard 2000 --worlds 2048 --first-world 14336
 run c3 500 --worlds 4096 --width 128 --height 128 --wall
 run c5 100 --worlds 4096 --width 256 --height 256 --textured --mode Raytracer
 run c5bvh 30 --worlds 4096 --width 256 --height 256 --textured --mode Raytracer --variant 2
+run c5raster 100 --worlds 4096 --width 256 --height 256 --textured --mode Raytracer --variant 3
 run bvh482 1000 --worlds 1024 --cubes 40
 run bvh1202 500 --worlds 1024 --cubes 100

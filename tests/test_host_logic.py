@@ -368,6 +368,16 @@ def test_dispatch_constants_follow_the_cu_count(native):
         assert f(0, 8, 0, 128, 64, cus) == 129
         # an explicit threshold is never raised
         assert f(40, 8, 0, 64, 64, cus) == 40 and f(200, small, 0, 64, 64, cus) == 65
+    # Raytracer-mode batches of small worlds that take the BVH path's flat kernel by default: BASELINE configs[4] does,
+    # an eighth of it does not, Rasterizer mode never, views of fewer than 16 tiles never, worlds beyond 64 triangles never
+    h = lib.mrx_dispatch_flat
+    h.restype = ctypes.c_int
+    h.argtypes = [ctypes.c_int] + [ctypes.c_uint32] * 6
+    assert h(1, 4096, 256, 256, 14, 2, 256) == 1 and h(1, 512, 256, 256, 14, 2, 256) == 0
+    assert h(1, 3072, 256, 256, 14, 2, 256) == 1 and h(1, 3071, 256, 256, 14, 2, 256) == 0
+    assert h(0, 4096, 256, 256, 14, 2, 256) == 0 and h(1, 16384, 128, 128, 14, 2, 256) == 0
+    assert h(1, 4096, 256, 256, 65, 2, 256) == 0 and h(1, 4096, 256, 256, 14, 65, 256) == 0
+    assert h(1, 512, 256, 256, 14, 2, 32) == 1 and h(1, 383, 256, 256, 14, 2, 32) == 0
     # the MI355X values the measurements were taken at (profiles/r03_bvh_threshold.txt)
     assert f(0, 640, 1, 64, 64, 256) == 65 and f(0, 641, 0, 64, 64, 256) == 91 and f(0, 1025, 0, 64, 64, 256) == 129
 

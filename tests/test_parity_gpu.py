@@ -221,18 +221,19 @@ def test_config_c4_last_shard_of_16384_worlds(native):
     assert_parity(fetch(r, visibility=False), render_oracle(desc, want_ids=False))
 
 
-@pytest.mark.parametrize("variant", [0, 2], ids=["default-dispatch", "bvh-path"])
+@pytest.mark.parametrize("variant", [0, 3], ids=["default-dispatch-bvh-path", "raster-kernels"])
 def test_config_c5_4096_worlds_256_textured_raytracer(native, monkeypatch, variant):
     # BASELINE configs[4] at its full size: every pixel of every view, colour,
-    # depth and segmask (3 GiB of output on the card) -- through the kernel the
-    # dispatch picks for 14-triangle worlds, and through the BVH ray-trace path
-    # the config names (mgr.cpp:443-492)
+    # depth and segmask (3 GiB of output on the card) -- through the BVH ray-trace path
+    # the config names (mgr.cpp:443-492), which the default dispatch picks for this
+    # batch since round 4 (the flat kernel, raster.hpp bvhDispatchFlat), and through
+    # the tiled raster kernel (kernel_variant 3)
     if variant:
         monkeypatch.setenv("MADRONA_MI355_KERNEL", str(variant))
     desc = scenes.synthetic_scene(4096, width=256, height=256, textured=True,
                                   render_mode="Raytracer")
     r = make_product(desc, visibility=False)
-    assert r.render_path() == ("bvh" if variant else "raster")
+    assert r.render_path() == ("raster" if variant else "bvh")
     got = fetch(r, visibility=False, raytracer=True)
     assert got["rgb"].shape == (4096, 256, 256, 4) and got["segmask"].dtype == np.int32
     del r
